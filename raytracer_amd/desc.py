@@ -1,0 +1,121 @@
+"""Plain-data scene description shared by every caller of the C boundary.
+
+The records mirror, field for field, the POD structs declared in ``include/rt_hip.h``
+(numpy structured dtypes with C alignment + ctypes mirrors of the top-level structs).
+Nothing here computes anything: it is the wire format between the host-side scene API
+(``raytracer_amd.scene``) and the shared library.
+
+Reference facts encoded here: material type bits (material.h:10-16), node kinds
+(Surface.h:50-56), sampler / integrator defaults (scene.h:52-54), octree defaults
+(octree.h:26,50).
+"""
+import ctypes as C
+
+import numpy as np
+
+# material type bits -- material.h:10-16
+MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MAT_MONTECARLO = 1, 2, 4, 8
+# object kinds -- Surface.h:50-56 (+ the triangle mesh this build adds)
+OBJ_SPHERE, OBJ_GROUND, OBJ_WALL_Z, OBJ_WALL_X, OBJ_MESH = 1, 2, 3, 4, 5
+LIGHT_SPHERE, LIGHT_FACE = 1, 2
+MISS = 0xFFFFFFFF
+
+INFINITE = 1e10   # definitions.h:5
+ZERO = 1e-9       # definitions.h:6
+PI = 3.1415926    # definitions.h:7 (7 digits, kept on purpose)
+
+OBJECT_DT = np.dtype([("type", "<i4"), ("material", "<i4"), ("mesh", "<i4"), ("reserved", "<i4"),
+                      ("p", "<f8", (4,))], align=True)
+MATERIAL_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("emission", "<f8", (3,)),
+                        ("color", "<f8", (3,)), ("blur", "<f8"), ("atten", "<f8", (3,)),
+                        ("nr", "<f8")], align=True)
+LIGHT_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("pos", "<f8", (3,)), ("radius", "<f8"),
+                     ("normal", "<f8", (3,)), ("up", "<f8", (3,)), ("right", "<f8", (3,)),
+                     ("width", "<f8"), ("height", "<f8"), ("diffuse", "<f8", (3,))], align=True)
+RAY_DT = np.dtype([("e", "<f8", (3,)), ("d", "<f8", (3,))], align=True)
+
+assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 96 and LIGHT_DT.itemsize == 152
+
+
+class MeshC(C.Structure):
+    _fields_ = [("tris", C.c_void_p), ("ntris", C.c_uint64)]
+
+
+class SceneDescC(C.Structure):
+    _fields_ = [("objects", C.c_void_p), ("nobjects", C.c_uint64),
+                ("materials", C.c_void_p), ("nmaterials", C.c_uint64),
+                ("lights", C.c_void_p), ("nlights", C.c_uint64),
+                ("meshes", C.c_void_p), ("nmeshes", C.c_uint64),
+                ("background", C.c_double * 3),
+                ("tri_box_pad", C.c_double),
+                ("octree_max_size", C.c_int32), ("octree_overlap_tol", C.c_int32),
+                ("octree_max_depth", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("e", C.c_double * 3), ("llc", C.c_double * 3), ("u", C.c_double * 3),
+                ("v", C.c_double * 3), ("width", C.c_double), ("height", C.c_double)]
+
+
+class RenderParamsC(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("n", C.c_int32), ("m", C.c_int32),
+                ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
+                ("max_jump", C.c_int32), ("rus_jump", C.c_int32),
+                ("seed", C.c_uint64), ("face_forward", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SceneDesc:
+    """A flattened scene: objects in Group child order, materials, lights, triangle meshes."""
+
+    def __init__(self, objects, materials, lights, meshes, background=(0.0, 0.0, 0.0),
+                 tri_box_pad=1e-7, octree_max_size=128, octree_overlap_tol=3, octree_max_depth=12):
+        self.objects = np.ascontiguousarray(objects, dtype=OBJECT_DT)
+        self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DT)
+        self.lights = np.ascontiguousarray(lights, dtype=LIGHT_DT)
+        self.meshes = [np.ascontiguousarray(m, dtype=np.float64).reshape(-1, 9) for m in meshes]
+        self.background = tuple(float(x) for x in background)
+        self.tri_box_pad = float(tri_box_pad)
+        self.octree_max_size = int(octree_max_size)
+        self.octree_overlap_tol = int(octree_overlap_tol)
+        self.octree_max_depth = int(octree_max_depth)
+
+    def to_c(self):
+        """Return (SceneDescC, keepalive) -- keepalive must outlive the call that reads it."""
+        mesh_arr = (MeshC * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            mesh_arr[i].tris = m.ctypes.data
+            mesh_arr[i].ntris = m.shape[0]
+        d = SceneDescC()
+        d.objects, d.nobjects = self.objects.ctypes.data, len(self.objects)
+        d.materials, d.nmaterials = self.materials.ctypes.data, len(self.materials)
+        d.lights, d.nlights = self.lights.ctypes.data, len(self.lights)
+        d.meshes, d.nmeshes = C.addressof(mesh_arr), len(self.meshes)
+        d.background = (C.c_double * 3)(*self.background)
+        d.tri_box_pad = self.tri_box_pad
+        d.octree_max_size = self.octree_max_size
+        d.octree_overlap_tol = self.octree_overlap_tol
+        d.octree_max_depth = self.octree_max_depth
+        return d, (mesh_arr, self)
+
+    @property
+    def prim_base(self):
+        """Global primitive id of each object's first primitive (mesh: one id per triangle)."""
+        base, out = 0, []
+        for o in self.objects:
+            out.append(base)
+            base += self.meshes[int(o["mesh"])].shape[0] if int(o["type"]) == OBJ_MESH else 1
+        return np.asarray(out + [base], dtype=np.int64)
+
+
+def render_params(width, height, n, m=None, sample_begin=0, sample_end=None, max_jump=40,
+                  rus_jump=12, seed=1243, face_forward=False):
+    """Sampler/integrator parameters; defaults are the reference's (scene.h:52-54, scene.cpp:22)."""
+    m = n if m is None else m
+    p = RenderParamsC()
+    p.width, p.height, p.n, p.m = int(width), int(height), int(n), int(m)
+    p.sample_begin = int(sample_begin)
+    p.sample_end = int(n * m if sample_end is None else sample_end)
+    p.max_jump, p.rus_jump = int(max_jump), int(rus_jump)
+    p.seed = int(seed)
+    p.face_forward = 1 if face_forward else 0
+    return p
