@@ -1,0 +1,184 @@
+/*
+ * rt_hip.h -- C ABI of librt_hip.so: octree ray intersection + Monte-Carlo path tracing on
+ * MI355X (gfx950) behind the reference renderer's scene model.
+ *
+ * Conventions (the reference's own, scene.cpp:54,62,191; scene.h:74-79): every entry point
+ * returns int, 0 = ok, negative = error; rt_last_error() gives the text; nothing throws
+ * across the boundary.  All POD inputs are borrowed for the duration of the call and copied.
+ * Entry points without a _host suffix take DEVICE pointers for bulk inputs/outputs and a HIP
+ * stream (void*, NULL = default stream) and return after enqueueing; _host variants take
+ * host pointers, allocate temporaries, synchronise and copy back (they are the drop-in for
+ * code that reads Scene::colorArray_ on the host).
+ *
+ * A scene handle belongs to the device that was current when it was created and must not be
+ * used from two threads at once (the reference clones its scene per thread for the same
+ * reason, scene.cpp:150).  Upload is immutable: any number of trace/render calls may follow.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Material::Type bit flags -- material.h:10-16 */
+enum { RT_MAT_NORMAL = 1, RT_MAT_SPECULAR = 2, RT_MAT_TRANSPARENT = 4, RT_MAT_MONTECARLO = 8 };
+/* Node kinds -- Surface.h:50-56; RT_OBJ_MESH is the triangle mesh drawable this library adds
+ * where the reference has HeartShape / ImplicitSurface (Surface.h:131-174) */
+enum { RT_OBJ_SPHERE = 1, RT_OBJ_GROUND = 2, RT_OBJ_WALL_Z = 3, RT_OBJ_WALL_X = 4, RT_OBJ_MESH = 5 };
+/* SphereLight / FaceLight -- light.h:32-73 */
+enum { RT_LIGHT_SPHERE = 1, RT_LIGHT_FACE = 2 };
+
+#define RT_MISS 0xFFFFFFFFu
+
+/* One child of the scene's Group, in Group::addChild order (Surface.cpp:154-158). */
+typedef struct {
+    int32_t type;      /* RT_OBJ_* */
+    int32_t material;  /* Node::setMaterial, Surface.cpp:25-31 */
+    int32_t mesh;      /* index into rt_scene_desc.meshes (RT_OBJ_MESH only) */
+    int32_t reserved;
+    double  p[4];      /* Sphere(center, radius): cx,cy,cz,r (Surface.h:98) ; Ground(y) / Wall_z(z) / Wall_x(x): p[0] */
+} rt_object;
+
+/* Plain Monte-Carlo Material -- material.h:55-66, ctors material.cpp:14-23 */
+typedef struct {
+    int32_t type;
+    int32_t reserved;
+    double  emission[3];
+    double  color[3];  /* getColor() == diffuse */
+    double  blur;      /* getMirrorBlur() */
+    double  atten[3];  /* getAttenuation() */
+    double  nr;        /* getRefraCoef() */
+} rt_material;
+
+/* SphereLight(pos, radius, emission) light.cpp:109-116 ; FaceLight(...) light.cpp:50-56 */
+typedef struct {
+    int32_t type;
+    int32_t reserved;
+    double  pos[3];
+    double  radius;
+    double  normal[3];      /* normalised by the FaceLight ctor */
+    double  up[3];
+    double  right[3];       /* up ^ normal, not normalised */
+    double  width, height;
+    double  diffuse[3];     /* getDiffuse() */
+} rt_light;
+
+typedef struct {
+    const double *tris;     /* ntris x 9 doubles (v0 v1 v2), host memory */
+    uint64_t ntris;
+} rt_mesh;
+
+/* What Scene::setRootNode / addLight / setClearColor assemble (scene.cpp:68-93). */
+typedef struct {
+    const rt_object   *objects;   uint64_t nobjects;
+    const rt_material *materials; uint64_t nmaterials;
+    const rt_light    *lights;    uint64_t nlights;
+    const rt_mesh     *meshes;    uint64_t nmeshes;
+    double  background[3];      /* backGround_ */
+    double  tri_box_pad;        /* added on all six sides of a triangle's AABB (flat boxes are never inserted: algorithms.h:329-333) */
+    int32_t octree_max_size;    /* Octree(maxSize = 128), octree.h:50 */
+    int32_t octree_overlap_tol; /* OctreeNode::OverlapTolerance = 3, octree.h:26 */
+    int32_t octree_max_depth;   /* depth guard (the reference has none), <= 15 */
+    int32_t reserved;
+} rt_scene_desc;
+
+/* Camera members after Camera::init -- camera.cpp:37-48 */
+typedef struct {
+    double e[3];
+    double llc[3];   /* leftLowerCorner */
+    double u[3], v[3];
+    double width, height;
+} rt_camera;
+
+/* Scene's private sampler / integrator constants, made settable -- scene.h:52-54 */
+typedef struct {
+    int32_t  width, height;            /* setPixels, scene.cpp:52-58 */
+    int32_t  n, m;                     /* RTObject::setRandomSize(n, m): spp = n*m */
+    int32_t  sample_begin, sample_end; /* slice of the n*m sample indices this call renders */
+    int32_t  max_jump, rus_jump;       /* maxJump_ = 40, rusJump_ = 12 */
+    uint64_t seed;                     /* replaces srand(1243), scene.cpp:22 */
+    int32_t  face_forward;             /* 0 = raw normals as in scene.cpp:218,233 */
+    int32_t  reserved;
+} rt_render_params;
+
+typedef struct { double e[3]; double d[3]; } rt_ray; /* types.h:180-184 */
+
+typedef struct rt_scene rt_scene;
+
+const char *rt_last_error(void);
+/* Number of visible HIP devices, or a negative error. */
+int rt_device_count(void);
+/* Select the device used by this thread's later calls. */
+int rt_set_device(int device);
+
+/* Scene assembly + one-time upload.  Builds one octree per mesh on the host with the
+ * reference policy (OctreeNode::insertObject / createChildren, octree.cpp:61-108), flattens
+ * it into device-resident arrays and copies spheres, planes, materials and lights. */
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
+int rt_scene_destroy(rt_scene *scene);
+/* out[0..5] = nodes, leaves, object refs, refs at inner nodes, max depth, lost primitives */
+int rt_scene_octree_stats(const rt_scene *scene, int mesh, uint64_t out[6]);
+
+/* Camera::Camera -> init, camera.cpp:5-8,37-48 (host arithmetic) */
+int rt_camera_init(const double look_from[3], const double look_at[3], const double vup[3],
+                   double vfov, double aspect, rt_camera *out);
+
+/* Closest hit for a batch of rays = group_->calHit(ray, t0, t1, &rec) (scene.cpp:202,
+ * Surface.cpp:160-181, octree.cpp:285-376).  prim_id[i] = global primitive id (objects in
+ * Group order; a mesh contributes one id per triangle) or RT_MISS; t, normal nullable.
+ * counters (nullable, 4 x u64, device) += {rays, inner-node visits, leaf visits, primitive tests}. */
+int rt_trace_rays(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, double t1,
+                  uint32_t *prim_id, double *t, double *normal, uint64_t *counters, void *stream);
+int rt_trace_rays_host(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, double t1,
+                       uint32_t *prim_id, double *t, double *normal, uint64_t *counters);
+
+/* Primary-ray hit / id buffer: Camera::getRay((x+.5)/W, (y+.5)/H) (camera.cpp:24-31, float
+ * arguments) then the closest hit; row-major [y][x], y = 0 is the bottom row. */
+int rt_trace_primary(rt_scene *scene, const rt_camera *cam, int width, int height,
+                     uint32_t *prim_id, double *t, uint64_t *counters, void *stream);
+int rt_trace_primary_host(rt_scene *scene, const rt_camera *cam, int width, int height,
+                          uint32_t *prim_id, double *t, uint64_t *counters);
+
+/* The batch hook the reference declares but never defines:
+ *   void getRayColor(Scene*, std::vector<Ray>, double t0, double t1, int jumptime,
+ *                    std::vector<Color>&)            (cudaRayTracer.h:4, scene.h:57)
+ * out[i] = scene->rayColor(rays[i], t0, t1, jumptime) (scene.cpp:194-304); ray i draws the
+ * sample stream of pixel i, sample 0 of a 1x1 table.  out = n x 3 doubles. */
+int rt_ray_color(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, double t1,
+                 int jumptime, const rt_render_params *params, double *out, uint64_t *counters,
+                 void *stream);
+int rt_ray_color_host(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, double t1,
+                      int jumptime, const rt_render_params *params, double *out, uint64_t *counters);
+
+/* Scene::run / runParallelly (scene.cpp:95-172) for every pixel and the sample slice
+ * [sample_begin, sample_end): radiance_sum[y][x][3] += sum of rayColor over the slice
+ * (not divided, not clamped -- the clamp comes after averaging, scene.cpp:112-113, so
+ * partial sums from several devices can be added first). */
+int rt_render(rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
+              double *radiance_sum, uint64_t *counters, void *stream);
+int rt_render_host(rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
+                   double *radiance_sum, uint64_t *counters);
+
+/* Synchronises `stream` and reports a failure recorded by an earlier rt_render / rt_ray_color
+ * launch on this scene (a lane ran out of pending-ray slots; the slot count is an upper bound
+ * derived from the materials, so this is a should-not-happen check).  The _host variants call
+ * it themselves.  No counterpart in the reference. */
+int rt_scene_check(rt_scene *scene, void *stream);
+
+/* colorArray_ -> bytes: average, Vec4::regularize (types.h:167-177), int(c*255) stored B,G,R
+ * (scene.cpp:183-185).  bgr = height x width x 3 bytes, bottom row first. */
+int rt_resolve_bgr8(const double *radiance_sum, int width, int height, int spp, uint8_t *bgr,
+                    void *stream);
+int rt_resolve_bgr8_host(const double *radiance_sum, int width, int height, int spp, uint8_t *bgr);
+
+/* Snapshot (bmpgenerator.cpp:3-45) with fixed-width header fields: 14 + 40 byte headers,
+ * 24 bpp, bottom-up rows, no row padding (as the reference writes it). */
+int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

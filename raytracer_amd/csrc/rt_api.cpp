@@ -1,0 +1,482 @@
+// rt_api.cpp -- the C ABI of librt_hip.so (declared in include/rt_hip.h): scene upload,
+// workspace management and kernel launches.  No CPU rendering path exists in this library:
+// every trace / render entry point runs the gfx950 kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+#include "rt_kernels.h"
+#include "rt_octree.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &m) { g_err = m; return -1; }
+int fail_hip(const char *what, hipError_t e) { g_err = std::string(what) + ": " + hipGetErrorString(e); return -2; }
+
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail_hip(#expr, _e); } while (0)
+
+struct MeshInfo { uint64_t stats[6]; };
+
+template <class T>
+hipError_t upload(const std::vector<T> &v, void **dptr)
+{
+    size_t bytes = v.size() * sizeof(T);
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice);
+    return e;
+}
+
+} // namespace
+
+struct rt_scene {
+    int device = 0;
+    int num_cu = 0;
+    DevScene dev{};
+    std::vector<void *> allocs;
+    std::vector<MeshInfo> meshes;
+    std::vector<rt_material> materials;
+    int nlights = 0;
+    // path-tracing workspace (grown on demand, reused by later calls)
+    uint64_t *d_jobs = nullptr;
+    size_t jobs_bytes = 0;
+    uint32_t *d_ctrl = nullptr;   // [0] work counter, [1] overflow flag
+    int blocks_per_cu = 0;
+};
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail_hip("hipGetDeviceCount", e);
+    return n;
+}
+
+int rt_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int rt_camera_init(const double from[3], const double at[3], const double vup[3], double vfov, double aspect, rt_camera *out)
+{
+    if (!from || !at || !vup || !out) return fail("rt_camera_init: null argument");
+    // Camera::init, camera.cpp:37-48 (PI is the reference's 7-digit constant, definitions.h:7)
+    const double PI = 3.1415926;
+    auto sub = [](const double *a, const double *b, double *r) { for (int k = 0; k < 3; k++) r[k] = a[k] - b[k]; };
+    auto length = [](const double *a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
+    auto normalize = [&](double *a) { double s = 1 / length(a); for (int k = 0; k < 3; k++) a[k] = a[k] * s; };
+    auto cross = [](const double *l, const double *r, double *o) {
+        o[0] = l[1] * r[2] - r[1] * l[2]; o[1] = l[2] * r[0] - l[0] * r[2]; o[2] = l[0] * r[1] - r[0] * l[1];
+    };
+    double tmp[3], w[3], u[3], v[3];
+    sub(at, from, tmp);
+    double d = length(tmp);
+    sub(from, at, w); normalize(w);
+    cross(vup, w, u); normalize(u);
+    cross(w, u, v); normalize(v);
+    double height = std::tan(vfov * PI / 180 / 2) * d * 2;
+    double width = height * aspect;
+    for (int k = 0; k < 3; k++) {
+        out->e[k] = from[k];
+        out->u[k] = u[k];
+        out->v[k] = v[k];
+        out->llc[k] = (at[k] - v[k] * (height / 2)) - u[k] * (width / 2);
+    }
+    out->width = width;
+    out->height = height;
+    return 0;
+}
+
+int rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return 0;
+    (void)hipSetDevice(s->device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->d_jobs) (void)hipFree(s->d_jobs);
+    if (s->d_ctrl) (void)hipFree(s->d_ctrl);
+    delete s;
+    return 0;
+}
+
+int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
+{
+    if (!d || !out) return fail("rt_scene_create: null argument");
+    *out = nullptr;
+    if ((d->nobjects && !d->objects) || (d->nmaterials && !d->materials) || (d->nlights && !d->lights) || (d->nmeshes && !d->meshes))
+        return fail("rt_scene_create: null array with non-zero count");
+    if (d->nobjects > 1u << 20 || d->nlights > 1024) return fail("rt_scene_create: too many objects or lights");
+    const int max_size = d->octree_max_size > 0 ? d->octree_max_size : 128;
+    const int tol = d->octree_overlap_tol > 0 ? d->octree_overlap_tol : 3;
+    const int max_depth = d->octree_max_depth > 0 ? d->octree_max_depth : 12;
+    if (max_depth > 15) return fail("rt_scene_create: octree_max_depth must be <= 15");
+
+    for (uint64_t i = 0; i < d->nmaterials; i++) {
+        const rt_material &m = d->materials[i];
+        if (!(m.type & RT_MAT_MONTECARLO))
+            return fail("rt_scene_create: material " + std::to_string(i) + " is not a MONTECARLO material (the legacy Phong branch is not on this path)");
+        if ((m.type & RT_MAT_TRANSPARENT) && !(m.nr > 0)) return fail("rt_scene_create: transparent material needs nr > 0");
+    }
+    for (uint64_t i = 0; i < d->nlights; i++) {
+        int t = d->lights[i].type;
+        if (t != RT_LIGHT_SPHERE && t != RT_LIGHT_FACE) return fail("rt_scene_create: unknown light type");
+    }
+
+    // one octree per mesh, concatenated into scene-wide arrays
+    std::vector<FlatNode> nodes;
+    std::vector<uint32_t> obj_index;
+    std::vector<double> tris;
+    std::vector<uint32_t> mesh_root(d->nmeshes), mesh_tri_base(d->nmeshes);
+    std::vector<uint64_t> mesh_ntris(d->nmeshes);
+    std::vector<MeshInfo> infos(d->nmeshes);
+    for (uint64_t mi = 0; mi < d->nmeshes; mi++) {
+        const rt_mesh &m = d->meshes[mi];
+        if (m.ntris && !m.tris) return fail("rt_scene_create: mesh with null triangle array");
+        FlatTree ft;
+        std::string err;
+        if (!build_octree(m.tris, m.ntris, d->tri_box_pad, max_size, tol, max_depth, ft, err))
+            return fail("rt_scene_create: mesh " + std::to_string(mi) + ": " + err);
+        const uint64_t node_base = nodes.size(), idx_base = obj_index.size(), tri_base = tris.size() / 9;
+        if (node_base + ft.nodes.size() >= 0xFFFFFFF0ull || idx_base + ft.obj_index.size() >= 0xFFFFFFF0ull || tri_base + m.ntris >= 0xFFFFFFF0ull)
+            return fail("rt_scene_create: scene too large for 32-bit indices");
+        mesh_root[mi] = (uint32_t)node_base;
+        mesh_tri_base[mi] = (uint32_t)tri_base;
+        mesh_ntris[mi] = m.ntris;
+        for (FlatNode f : ft.nodes) {
+            if (f.child_base) f.child_base += (uint32_t)node_base;
+            f.obj_begin += (uint32_t)idx_base;
+            nodes.push_back(f);
+        }
+        for (uint32_t t : ft.obj_index) obj_index.push_back(t + (uint32_t)tri_base);
+        tris.insert(tris.end(), ft.tri_rec.begin(), ft.tri_rec.end());
+        std::memcpy(infos[mi].stats, ft.stats, sizeof ft.stats);
+    }
+
+    std::vector<DevObject> objs(d->nobjects);
+    uint64_t prim = 0;
+    for (uint64_t i = 0; i < d->nobjects; i++) {
+        const rt_object &o = d->objects[i];
+        DevObject &q = objs[i];
+        std::memset(&q, 0, sizeof q);
+        if (o.type < RT_OBJ_SPHERE || o.type > RT_OBJ_MESH) return fail("rt_scene_create: object " + std::to_string(i) + " has an unknown type");
+        if (o.material < 0 || (uint64_t)o.material >= d->nmaterials) return fail("rt_scene_create: object " + std::to_string(i) + " has no valid material");
+        q.type = o.type; q.material = o.material;
+        for (int k = 0; k < 4; k++) q.p[k] = o.p[k];
+        q.prim_base = (uint32_t)prim;
+        if (o.type == RT_OBJ_MESH) {
+            if (o.mesh < 0 || (uint64_t)o.mesh >= d->nmeshes) return fail("rt_scene_create: object " + std::to_string(i) + " has a bad mesh index");
+            q.root = mesh_root[o.mesh];
+            q.tri_base = mesh_tri_base[o.mesh];
+            prim += mesh_ntris[o.mesh];
+        } else {
+            prim += 1;
+        }
+        if (prim >= 0xFFFFFFFFull) return fail("rt_scene_create: more than 2^32-1 primitives");
+    }
+
+    rt_scene *s = new (std::nothrow) rt_scene;
+    if (!s) return fail("rt_scene_create: out of memory");
+    hipError_t e = hipGetDevice(&s->device);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, s->device);
+        if (e == hipSuccess) s->num_cu = prop.multiProcessorCount;
+    }
+    std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
+    std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
+    void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr;
+    auto up = [&](auto &vec, void **dst) {
+        if (e != hipSuccess) return;
+        e = upload(vec, dst);
+        if (*dst) s->allocs.push_back(*dst);
+    };
+    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(obj_index, &p_idx); up(tris, &p_tris);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
+    if (e != hipSuccess) { rt_scene_destroy(s); return fail_hip("scene upload", e); }
+    s->dev.objects = (const DevObject *)p_obj;
+    s->dev.materials = (const rt_material *)p_mat;
+    s->dev.lights = (const rt_light *)p_light;
+    s->dev.nodes = (const FlatNode *)p_nodes;
+    s->dev.obj_index = (const uint32_t *)p_idx;
+    s->dev.tris = (const double *)p_tris;
+    s->dev.nobjects = (int32_t)d->nobjects;
+    s->dev.nlights = (int32_t)d->nlights;
+    for (int k = 0; k < 3; k++) s->dev.background[k] = d->background[k];
+    s->meshes = infos;
+    s->materials = mats;
+    s->nlights = (int)d->nlights;
+    *out = s;
+    return 0;
+}
+
+int rt_scene_octree_stats(const rt_scene *s, int mesh, uint64_t out[6])
+{
+    if (!s || !out) return fail("rt_scene_octree_stats: null argument");
+    if (mesh < 0 || (size_t)mesh >= s->meshes.size()) return fail("rt_scene_octree_stats: bad mesh index");
+    std::memcpy(out, s->meshes[mesh].stats, 6 * sizeof(uint64_t));
+    return 0;
+}
+
+int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double t1, uint32_t *prim_id, double *t,
+                  double *normal, uint64_t *counters, void *stream)
+{
+    if (!s) return fail("rt_trace_rays: null scene");
+    if (n && (!rays || !prim_id)) return fail("rt_trace_rays: null buffer");
+    if (n > 0xFFFFFFFFull * 128) return fail("rt_trace_rays: batch too large");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_trace_rays(s->dev, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
+    return 0;
+}
+
+int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *prim_id, double *t, uint64_t *counters, void *stream)
+{
+    if (!s || !cam) return fail("rt_trace_primary: null argument");
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail("rt_trace_primary: bad image size");
+    if (!prim_id) return fail("rt_trace_primary: null buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(launch_trace_primary(s->dev, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
+    return 0;
+}
+
+// Upper bound on the pending rays one lane can hold: a vertex pushes one record per bounce
+// ray and per light; records left behind when the lane follows a bounce ray stay until that
+// whole subtree is done, and paths are at most max_jump vertices deep.
+static int pending_capacity(const rt_scene *s, int max_jump)
+{
+    int max_left = 0, max_push = 1;
+    for (const rt_material &m : s->materials) {
+        int lobes = ((m.type & RT_MAT_NORMAL) ? 1 : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 1 : 0);
+        int push = ((m.type & RT_MAT_NORMAL) ? 1 + s->nlights : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 2 : 0);
+        int left;
+        if (lobes <= 1 && !(m.type & RT_MAT_TRANSPARENT)) left = 0;   // shadow rays are served before the bounce ray
+        else left = push - 1;
+        if (left > max_left) max_left = left;
+        if (push > max_push) max_push = push;
+    }
+    return max_left * (max_jump + 1) + max_push + 1;
+}
+
+static int render_common(rt_scene *s, RenderArgs &A, uint64_t total_items, hipStream_t st)
+{
+    if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
+    if (!s->blocks_per_cu) s->blocks_per_cu = render_blocks_per_cu();
+    uint64_t blocks = (uint64_t)(s->num_cu > 0 ? s->num_cu : 256) * s->blocks_per_cu;
+    uint64_t need_blocks = (total_items + RT_BLOCK - 1) / RT_BLOCK;
+    if (need_blocks < blocks) blocks = need_blocks;
+    if (blocks == 0) return 0;
+    const uint64_t nlanes = blocks * RT_BLOCK;
+    A.stack_cap = pending_capacity(s, A.max_jump);
+    size_t bytes = (size_t)A.stack_cap * JOB_FIELDS * sizeof(uint64_t) * nlanes;
+    if (bytes > s->jobs_bytes) {
+        if (s->d_jobs) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(s->d_jobs)); s->d_jobs = nullptr; s->jobs_bytes = 0; }
+        HIP_TRY(hipMalloc((void **)&s->d_jobs, bytes));
+        s->jobs_bytes = bytes;
+    }
+    A.jobs = s->d_jobs;
+    A.next_work = s->d_ctrl;
+    A.overflow = s->d_ctrl + 1;
+    HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 8, st));
+    HIP_TRY(launch_render(s->dev, A, (unsigned)blocks, st));
+    return 0;
+}
+
+static int fill_args(const rt_render_params *p, RenderArgs &A, bool batch)
+{
+    if (!p) return fail("render: null params");
+    std::memset(&A, 0, sizeof A);
+    A.max_jump = p->max_jump; A.rus_jump = p->rus_jump; A.seed = p->seed; A.face_forward = p->face_forward;
+    if (batch) { A.n = A.m = 1; A.sample_begin = 0; A.sample_end = 1; return 0; }
+    if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536) return fail("render: bad image size");
+    if (p->n <= 0 || p->m <= 0 || (int64_t)p->n * p->m > (1 << 24)) return fail("render: bad jitter table size");
+    if (p->sample_begin < 0 || p->sample_end > p->n * p->m || p->sample_begin > p->sample_end) return fail("render: bad sample range");
+    A.width = p->width; A.height = p->height; A.n = p->n; A.m = p->m;
+    A.sample_begin = p->sample_begin; A.sample_end = p->sample_end;
+    return 0;
+}
+
+int rt_ray_color(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double t1, int jumptime, const rt_render_params *p,
+                 double *out, uint64_t *counters, void *stream)
+{
+    if (!s) return fail("rt_ray_color: null scene");
+    if (n && (!rays || !out)) return fail("rt_ray_color: null buffer");
+    if (n >= 0xFFFFFFFFull) return fail("rt_ray_color: batch too large");
+    if (jumptime < 0) return fail("rt_ray_color: negative jumptime");
+    RenderArgs A;
+    if (int rc = fill_args(p, A, true)) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    A.batch = 1; A.rays = rays; A.nrays = n; A.t0 = t0; A.t1 = t1; A.jumptime = jumptime;
+    A.out = out; A.counters = counters;
+    return render_common(s, A, n, (hipStream_t)stream);
+}
+
+int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *radiance_sum, uint64_t *counters, void *stream)
+{
+    if (!s || !cam) return fail("rt_render: null argument");
+    if (!radiance_sum) return fail("rt_render: null buffer");
+    RenderArgs A;
+    if (int rc = fill_args(p, A, false)) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    A.cam = *cam; A.out = radiance_sum; A.counters = counters;
+    uint64_t items = (uint64_t)((A.width + 7) >> 3) * (uint64_t)((A.height + 7) >> 3) * 64ull;
+    if (items >= 0xFFFFFFFFull) return fail("rt_render: image too large");
+    return render_common(s, A, items, (hipStream_t)stream);
+}
+
+/* Reports whether any path-tracing launch on this scene ran out of pending-ray slots
+ * (cannot happen while pending_capacity() is an upper bound).  Synchronises `stream`. */
+int rt_scene_check(rt_scene *s, void *stream)
+{
+    if (!s) return fail("rt_scene_check: null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    uint32_t ctrl[2] = {0, 0};
+    HIP_TRY(hipMemcpy(ctrl, s->d_ctrl, 8, hipMemcpyDeviceToHost));
+    if (ctrl[1]) return fail("path tracing ran out of pending-ray slots");
+    return 0;
+}
+
+int rt_resolve_bgr8(const double *radiance_sum, int w, int h, int spp, uint8_t *bgr, void *stream)
+{
+    if (!radiance_sum || !bgr) return fail("rt_resolve_bgr8: null buffer");
+    if (w <= 0 || h <= 0 || spp <= 0) return fail("rt_resolve_bgr8: bad size");
+    HIP_TRY(launch_resolve(radiance_sum, (uint64_t)w * h, spp, bgr, (hipStream_t)stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- host-buffer variants
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+}
+
+int rt_trace_rays_host(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double t1, uint32_t *prim_id, double *t,
+                       double *normal, uint64_t *counters)
+{
+    if (!s) return fail("rt_trace_rays_host: null scene");
+    if (n && (!rays || !prim_id)) return fail("rt_trace_rays_host: null buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dr, dp, dt, dn, dc;
+    HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dp.alloc(n * 4)); HIP_TRY(dt.alloc(n * 8)); HIP_TRY(dn.alloc(n * 24)); HIP_TRY(dc.alloc(32));
+    if (n) HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dc.p, 0, 32));
+    if (int rc = rt_trace_rays(s, (const rt_ray *)dr.p, n, t0, t1, (uint32_t *)dp.p, (double *)dt.p, (double *)dn.p, (uint64_t *)dc.p, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (n) {
+        HIP_TRY(hipMemcpy(prim_id, dp.p, n * 4, hipMemcpyDeviceToHost));
+        if (t) HIP_TRY(hipMemcpy(t, dt.p, n * 8, hipMemcpyDeviceToHost));
+        if (normal) HIP_TRY(hipMemcpy(normal, dn.p, n * 24, hipMemcpyDeviceToHost));
+    }
+    if (counters) { uint64_t c[4]; HIP_TRY(hipMemcpy(c, dc.p, 32, hipMemcpyDeviceToHost)); for (int k = 0; k < 4; k++) counters[k] += c[k]; }
+    return 0;
+}
+
+int rt_trace_primary_host(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *prim_id, double *t, uint64_t *counters)
+{
+    if (!s || !cam || !prim_id) return fail("rt_trace_primary_host: null argument");
+    if (w <= 0 || h <= 0) return fail("rt_trace_primary_host: bad image size");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = (size_t)w * h;
+    DevBuf dp, dt, dc;
+    HIP_TRY(dp.alloc(n * 4)); HIP_TRY(dt.alloc(n * 8)); HIP_TRY(dc.alloc(32));
+    HIP_TRY(hipMemset(dc.p, 0, 32));
+    if (int rc = rt_trace_primary(s, cam, w, h, (uint32_t *)dp.p, (double *)dt.p, (uint64_t *)dc.p, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(prim_id, dp.p, n * 4, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(hipMemcpy(t, dt.p, n * 8, hipMemcpyDeviceToHost));
+    if (counters) { uint64_t c[4]; HIP_TRY(hipMemcpy(c, dc.p, 32, hipMemcpyDeviceToHost)); for (int k = 0; k < 4; k++) counters[k] += c[k]; }
+    return 0;
+}
+
+int rt_ray_color_host(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double t1, int jumptime, const rt_render_params *p,
+                      double *out, uint64_t *counters)
+{
+    if (!s) return fail("rt_ray_color_host: null scene");
+    if (n && (!rays || !out)) return fail("rt_ray_color_host: null buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dr, dout, dc;
+    HIP_TRY(dr.alloc(n * sizeof(rt_ray))); HIP_TRY(dout.alloc(n * 24)); HIP_TRY(dc.alloc(32));
+    if (n) HIP_TRY(hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dc.p, 0, 32));
+    if (int rc = rt_ray_color(s, (const rt_ray *)dr.p, n, t0, t1, jumptime, p, (double *)dout.p, (uint64_t *)dc.p, nullptr)) return rc;
+    if (int rc = rt_scene_check(s, nullptr)) return rc;
+    if (n) HIP_TRY(hipMemcpy(out, dout.p, n * 24, hipMemcpyDeviceToHost));
+    if (counters) { uint64_t c[4]; HIP_TRY(hipMemcpy(c, dc.p, 32, hipMemcpyDeviceToHost)); for (int k = 0; k < 4; k++) counters[k] += c[k]; }
+    return 0;
+}
+
+int rt_render_host(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *radiance_sum, uint64_t *counters)
+{
+    if (!s || !cam || !p || !radiance_sum) return fail("rt_render_host: null argument");
+    if (p->width <= 0 || p->height <= 0) return fail("rt_render_host: bad image size");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t bytes = (size_t)p->width * p->height * 24;
+    DevBuf dout, dc;
+    HIP_TRY(dout.alloc(bytes)); HIP_TRY(dc.alloc(32));
+    HIP_TRY(hipMemcpy(dout.p, radiance_sum, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dc.p, 0, 32));
+    if (int rc = rt_render(s, cam, p, (double *)dout.p, (uint64_t *)dc.p, nullptr)) return rc;
+    if (int rc = rt_scene_check(s, nullptr)) return rc;
+    HIP_TRY(hipMemcpy(radiance_sum, dout.p, bytes, hipMemcpyDeviceToHost));
+    if (counters) { uint64_t c[4]; HIP_TRY(hipMemcpy(c, dc.p, 32, hipMemcpyDeviceToHost)); for (int k = 0; k < 4; k++) counters[k] += c[k]; }
+    return 0;
+}
+
+int rt_resolve_bgr8_host(const double *radiance_sum, int w, int h, int spp, uint8_t *bgr)
+{
+    if (!radiance_sum || !bgr) return fail("rt_resolve_bgr8_host: null buffer");
+    if (w <= 0 || h <= 0 || spp <= 0) return fail("rt_resolve_bgr8_host: bad size");
+    const size_t n = (size_t)w * h;
+    DevBuf ds, db;
+    HIP_TRY(ds.alloc(n * 24)); HIP_TRY(db.alloc(n * 3));
+    HIP_TRY(hipMemcpy(ds.p, radiance_sum, n * 24, hipMemcpyHostToDevice));
+    if (int rc = rt_resolve_bgr8((const double *)ds.p, w, h, spp, (uint8_t *)db.p, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(bgr, db.p, n * 3, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Snapshot, bmpgenerator.cpp:3-45, with fixed-width fields (the reference's `unsigned long`
+// header members are 8 bytes on LP64 and would corrupt the file).
+int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename)
+{
+    if (!bgr || !filename) return fail("rt_save_bmp: null argument");
+    if (width <= 0 || height <= 0) return fail("rt_save_bmp: bad size");
+    const uint32_t size = (uint32_t)width * (uint32_t)height * 3u;
+    unsigned char hdr[54];
+    std::memset(hdr, 0, sizeof hdr);
+    auto put16 = [&](int off, uint16_t v) { hdr[off] = v & 0xff; hdr[off + 1] = v >> 8; };
+    auto put32 = [&](int off, uint32_t v) { for (int k = 0; k < 4; k++) hdr[off + k] = (v >> (8 * k)) & 0xff; };
+    put16(0, 0x4d42);            // bfType "BM"
+    put32(2, size + 54);         // bfSize
+    put32(10, 54);               // bfOffBits
+    put32(14, 40);               // biSize
+    put32(18, (uint32_t)width);
+    put32(22, (uint32_t)height); // positive: bottom-up rows
+    put16(26, 1);                // biPlanes
+    put16(28, 24);               // biBitCount
+    put32(34, size);             // biSizeImage
+    FILE *fp = std::fopen(filename, "wb");
+    if (!fp) return fail(std::string("rt_save_bmp: cannot open ") + filename);
+    bool ok = std::fwrite(hdr, 1, 54, fp) == 54 && std::fwrite(bgr, 1, size, fp) == size;
+    std::fclose(fp);
+    return ok ? 0 : fail("rt_save_bmp: short write");
+}
+
+} // extern "C"

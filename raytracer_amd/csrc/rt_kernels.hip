@@ -1,0 +1,792 @@
+// rt_kernels.hip -- gfx950 kernels: octree closest hit, primary-ray id buffer, and the
+// Monte-Carlo path-tracing loop (persistent wave64 lanes).
+//
+// Everything is fp64 and must be built with -ffp-contract=off: hit primitive ids are
+// compared bit for bit with a CPU evaluation of the same expressions, so the operation
+// order of the reference's Vec3 helpers (types.h:19-74), of hitBox (algorithms.h:208-236)
+// and of std::min / std::max is kept literally.
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+#define RT_INFINITE 1e10     // definitions.h:5
+#define RT_ZERO 1e-9         // definitions.h:6
+#define RT_PI 3.1415926      // definitions.h:7
+#define TRI_DET_EPS 1e-200
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 had(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }    // Vec4::operator&
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Vec3::operator^, types.h:66-74
+__device__ __forceinline__ V3 cross(V3 l, V3 r)
+{
+    return mk(l.y * r.z - r.y * l.z, l.z * r.x - l.x * r.z, l.x * r.y - r.x * l.y);
+}
+__device__ __forceinline__ double len(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// Vec3::normalize multiplies by the reciprocal, types.h:19-23
+__device__ __forceinline__ V3 norm(V3 a) { return a * (1 / len(a)); }
+__device__ __forceinline__ bool iszero(V3 a) { return fabs(a.x) < RT_ZERO && fabs(a.y) < RT_ZERO && fabs(a.z) < RT_ZERO; }
+// Vec3::reflact, types.h:37-40
+__device__ __forceinline__ V3 reflact(V3 d, V3 n)
+{
+    V3 proj = (-n) * dot(d, n);
+    return norm(proj * 2 + d);
+}
+__device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }   // std::min
+__device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }   // std::max
+
+// ------------------------------------------------------------------ counter-based sampler
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint64_t hash2(uint64_t a, uint64_t b)
+{
+    return mix64((a ^ (b * 0xD6E8FEB86659FD93ULL)) + 0x9E3779B97F4A7C15ULL);
+}
+__device__ __forceinline__ double u01(uint64_t x) { return (double)(x >> 11) * 0x1.0p-53; }
+// keyed permutation of [0,l) (Kensler 2013, "Correlated Multi-Jittered Sampling")
+__device__ inline uint32_t permute(uint32_t i, uint32_t l, uint32_t p)
+{
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    do {
+        i ^= p;              i *= 0xe170893du;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8;         i *= 0x0929eb3fu;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1;   i *= 1 | p >> 27;
+                             i *= 0x6935fa69u;
+        i ^= (i & w) >> 11;  i *= 0x74dcb303u;
+        i ^= (i & w) >> 2;   i *= 0x9e501cc3u;
+        i ^= (i & w) >> 2;   i *= 0xc860a3dfu;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    return (i + p) % l;
+}
+#define KEY_JITTER 0x4a495454ULL
+#define KEY_PATH   0x50415448ULL
+#define SLOT_BASE  16
+enum { BR_DIFFUSE = 1, BR_SPECULAR = 2, BR_REFLECT = 3, BR_REFRACT = 4 };
+enum { SLOT_RR = 0, SLOT_DIFF1 = 1, SLOT_DIFF2 = 2, SLOT_DISK = 3 };
+
+// Entry k of object `object_id`'s n x m jitter table for this pixel: the table of
+// RTObject::calRandom (RTObject.cpp:46-69) evaluated lazily -- stratum sigma(k) of a keyed
+// permutation stands for the shuffled slot, one jitter pair per stratum.
+__device__ inline void jitter_pair(uint64_t seed, uint64_t pixel, uint32_t object_id, uint32_t k,
+                                   uint32_t n, uint32_t m, double &a, double &b)
+{
+    uint64_t kp = hash2(hash2(seed, pixel), KEY_JITTER + object_id);
+    uint32_t sigma = permute(k, n * m, (uint32_t)(kp >> 32));
+    uint32_t j = sigma % n, i = sigma / n;
+    double nstep = 1.0 / n, mstep = 1.0 / m;
+    double xi1 = u01(hash2(kp, 2ULL * sigma));
+    double xi2 = u01(hash2(kp, 2ULL * sigma + 1));
+    a = j * nstep + nstep * xi1;
+    b = i * mstep + mstep * xi2;
+}
+__device__ __forceinline__ uint64_t path_root_key(uint64_t seed, uint64_t pixel, uint32_t k)
+{
+    return hash2(hash2(hash2(seed, pixel), KEY_PATH), k);
+}
+__device__ __forceinline__ double draw(uint64_t key, uint32_t slot) { return u01(hash2(key, SLOT_BASE + slot)); }
+
+// ------------------------------------------------------------------ intersection
+// algorithm::hitBox, algorithms.h:223-236
+__device__ __forceinline__ bool hit_box(const double *lo, const double *hi, V3 e, V3 d, double t0, double t1,
+                                        double &r0o, double &r1o)
+{
+    double ax = (lo[0] - e.x) / d.x, ay = (lo[1] - e.y) / d.y, az = (lo[2] - e.z) / d.z;
+    double bx = (hi[0] - e.x) / d.x, by = (hi[1] - e.y) / d.y, bz = (hi[2] - e.z) / d.z;
+    double r0 = smin(ax, bx), r1 = smax(ax, bx);
+    double m;
+    m = smin(ay, by); if (r0 < m) r0 = m;            // std::max_element over {x, y, z, t0}
+    m = smin(az, bz); if (r0 < m) r0 = m;
+    if (r0 < t0) r0 = t0;
+    m = smax(ay, by); if (m < r1) r1 = m;            // std::min_element over {x, y, z, t1}
+    m = smax(az, bz); if (m < r1) r1 = m;
+    if (t1 < r1) r1 = t1;
+    r0o = r0; r1o = r1;
+    return r0 <= r1;
+}
+
+struct Counters { uint32_t rays, inner, leaf, prim; };
+
+// Two-sided Moeller-Trumbore on the stored (v0, e1, e2) record; the octree payload test that
+// stands where BoxNode::calHit does in the reference (Surface.cpp:43-59).
+__device__ __forceinline__ bool tri_hit(const double *tr, V3 e, V3 d, double t0, double t1, double &tout)
+{
+    V3 v0 = ld3(tr), e1 = ld3(tr + 3), e2 = ld3(tr + 6);
+    V3 p = cross(d, e2);
+    double det = dot(e1, p);
+    if (!(fabs(det) >= TRI_DET_EPS)) return false;
+    double inv = 1.0 / det;
+    V3 s = e - v0;
+    double u = dot(s, p) * inv;
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    V3 q = cross(s, e1);
+    double v = dot(d, q) * inv;
+    if (!(v >= 0.0 && u + v <= 1.0)) return false;
+    double t = dot(e2, q) * inv;
+    if (!(t >= t0 && t <= t1)) return false;
+    tout = t;
+    return true;
+}
+
+// Octree::hit (octree.cpp:285-376): ordered depth-first search.  Per open inner node the LDS
+// stack keeps {child_base, visiting order (8 x 3 bits) | count << 24 | next << 28}.
+// The reference re-checks `minrec.t < next.t` before descending (octree.cpp:359); next.t is
+// the child's own slab entry distance, which the child visit recomputes bit-identically, so
+// the check is made there.
+template <int BLOCK>
+__device__ inline bool octree_hit(const DevScene &S, uint32_t root, V3 e, V3 d, double t0, double t1,
+                                  double &tout, uint32_t &pout, uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+{
+    const int tid = threadIdx.x;
+    double mint = t1 + 1;
+    uint32_t minprim = RT_MISS;
+    int sp = 0;
+    uint32_t cur = root;
+    bool have = true;
+    for (;;) {
+        if (have) {
+            const FlatNode *nd = S.nodes + cur;
+            double lo[3] = { nd->lo[0], nd->lo[1], nd->lo[2] };
+            double hi[3] = { nd->hi[0], nd->hi[1], nd->hi[2] };
+            const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count;
+            // per-axis plane distances; the node's own slab test and all 8 child tests use them
+            double alo[3], ahi[3];
+            alo[0] = (lo[0] - e.x) / d.x; alo[1] = (lo[1] - e.y) / d.y; alo[2] = (lo[2] - e.z) / d.z;
+            ahi[0] = (hi[0] - e.x) / d.x; ahi[1] = (hi[1] - e.y) / d.y; ahi[2] = (hi[2] - e.z) / d.z;
+            double bt0 = smin(alo[0], ahi[0]), bt1 = smax(alo[0], ahi[0]);
+            double m;
+            m = smin(alo[1], ahi[1]); if (bt0 < m) bt0 = m;
+            m = smin(alo[2], ahi[2]); if (bt0 < m) bt0 = m;
+            if (bt0 < t0) bt0 = t0;
+            m = smax(alo[1], ahi[1]); if (m < bt1) bt1 = m;
+            m = smax(alo[2], ahi[2]); if (m < bt1) bt1 = m;
+            if (t1 < bt1) bt1 = t1;
+            const bool hb = bt0 <= bt1;
+            if (cur == root) {
+                if (!hb) return false;                       // octree.cpp:291
+            } else if (mint < bt0) {
+                break;                                       // octree.cpp:359-361
+            }
+            if (child_base) c.inner++; else c.leaf++;
+            bool improved = false;
+            if (hb) {                                        // OctreeNode::hit, octree.cpp:19-38
+                double tempt = bt1, best = 0;
+                uint32_t bprim = RT_MISS;
+                for (uint32_t k = 0; k < obj_count; k++) {
+                    uint32_t ti = S.obj_index[obj_begin + k];
+                    double tt;
+                    c.prim++;
+                    if (tri_hit(S.tris + 9ull * ti, e, d, bt0, bt1, tt)) {
+                        if (tt <= tempt) { tempt = tt; best = tt; bprim = ti; }
+                    }
+                }
+                if (bprim != RT_MISS && best < mint) { mint = best; minprim = bprim; improved = true; }
+            }
+            have = false;
+            if (!child_base) {
+                if (improved) break;                         // octree.cpp:326-329
+            } else {
+                // 8 child slab tests (octree.cpp:337-343) from {lo, mid, hi} plane distances
+                double amid[3];
+                amid[0] = ((lo[0] + hi[0]) / 2 - e.x) / d.x;
+                amid[1] = ((lo[1] + hi[1]) / 2 - e.y) / d.y;
+                amid[2] = ((lo[2] + hi[2]) / 2 - e.z) / d.z;
+                double mnL[3], mxL[3], mnH[3], mxH[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    mnL[k] = smin(alo[k], amid[k]); mxL[k] = smax(alo[k], amid[k]);
+                    mnH[k] = smin(amid[k], ahi[k]); mxH[k] = smax(amid[k], ahi[k]);
+                }
+                double ct[8];
+                uint32_t hitmask = 0;
+#pragma unroll
+                for (int ci = 0; ci < 8; ci++) {
+                    // corner order of getChildBound: x-half, y-half, z-half of child ci
+                    const int hx = (ci == 1 || ci == 2 || ci == 5 || ci == 6), hy = (ci == 2 || ci == 3 || ci == 6 || ci == 7), hz = ci >> 2;
+                    double r0 = hx ? mnH[0] : mnL[0], r1 = hx ? mxH[0] : mxL[0];
+                    double q;
+                    q = hy ? mnH[1] : mnL[1]; if (r0 < q) r0 = q;
+                    q = hz ? mnH[2] : mnL[2]; if (r0 < q) r0 = q;
+                    if (r0 < t0) r0 = t0;
+                    q = hy ? mxH[1] : mxL[1]; if (q < r1) r1 = q;
+                    q = hz ? mxH[2] : mxL[2]; if (q < r1) r1 = q;
+                    if (t1 < r1) r1 = t1;
+                    ct[ci] = r0;
+                    if (r0 <= r1) hitmask |= 1u << ci;
+                }
+                // std::sort by entry distance (octree.cpp:344); equal keys keep child order
+                uint32_t order = 0, cnt = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (hitmask & (1u << i)) {
+                        uint32_t rank = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if (j == i) continue;
+                            if (hitmask & (1u << j)) {
+                                bool before = (j < i) ? !(ct[i] < ct[j]) : (ct[j] < ct[i]);
+                                rank += before ? 1u : 0u;
+                            }
+                        }
+                        order |= (uint32_t)i << (3 * rank);
+                        cnt++;
+                    }
+                }
+                if (cnt) {
+                    stk[0][sp][tid] = child_base;
+                    stk[1][sp][tid] = order | (cnt << 24);
+                    sp++;
+                }
+            }
+        } else {
+            if (sp == 0) break;
+            uint32_t w = stk[1][sp - 1][tid];
+            uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
+            if (pos == cnt) { sp--; continue; }
+            uint32_t child = (w >> (3 * pos)) & 7u;
+            stk[1][sp - 1][tid] = w + (1u << 28);
+            cur = stk[0][sp - 1][tid] + child;
+            have = true;
+        }
+    }
+    if (mint <= t1 && minprim != RT_MISS) { tout = mint; pout = minprim; return true; }
+    return false;
+}
+
+// Sphere::hit, Surface.cpp:73-111 (the tangent branch skips the [t0,t1] window)
+__device__ __forceinline__ bool sphere_hit(const double *p, V3 e, V3 d, double t0, double t1, double &tout)
+{
+    V3 oc = e - mk(p[0], p[1], p[2]);
+    double radius = p[3];
+    double doc = dot(d, oc);
+    double dieta = doc * doc - dot(d, d) * (dot(oc, oc) - radius * radius);
+    double deno = dot(d, d);
+    double pre = dot(-d, oc);
+    double t;
+    if (fabs(dieta) < RT_ZERO) {
+        t = pre / deno;
+    } else if (dieta > 0) {
+        double sq = sqrt(dieta);
+        double pt = (pre - sq) / deno;
+        double nt = (pre + sq) / deno;
+        bool f1 = (pt > t1 || pt < t0), f2 = (nt > t1 || nt < t0);
+        if (f1 && f2) return false;
+        t = !f1 ? pt : nt;
+    } else {
+        return false;
+    }
+    tout = t;
+    return true;
+}
+// Ground / Wall_z / Wall_x ::hit, Surface.cpp:124-133, 194-204, 217-226
+__device__ __forceinline__ bool plane_hit(int type, double coord, V3 e, V3 d, double t0, double t1, double &tout)
+{
+    double ee = (type == RT_OBJ_GROUND) ? e.y : (type == RT_OBJ_WALL_Z ? e.z : e.x);
+    double dd = (type == RT_OBJ_GROUND) ? d.y : (type == RT_OBJ_WALL_Z ? d.z : d.x);
+    if (ee > coord && dd < 0) {
+        double t = (ee - coord) / -dd;
+        if (t < t0 || t > t1) return false;
+        tout = t;
+        return true;
+    }
+    return false;
+}
+
+struct Hit { double t; int32_t obj; uint32_t prim; };
+
+// Group::hit, Surface.cpp:160-181: every child is tested, each hit shrinks t1
+template <int BLOCK>
+__device__ inline bool group_hit(const DevScene &S, V3 e, V3 d, double t0, double t1, Hit &h,
+                                 uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+{
+    bool flag = false;
+    c.rays++;
+    for (int i = 0; i < S.nobjects; i++) {
+        const DevObject &o = S.objects[i];
+        double t; uint32_t prim = 0;
+        bool hit;
+        if (o.type == RT_OBJ_SPHERE) hit = sphere_hit(o.p, e, d, t0, t1, t);
+        else if (o.type == RT_OBJ_MESH) hit = octree_hit<BLOCK>(S, o.root, e, d, t0, t1, t, prim, stk, c);
+        else hit = plane_hit(o.type, o.p[0], e, d, t0, t1, t);
+        if (hit) { flag = true; t1 = t; h.t = t; h.obj = i; h.prim = prim; }
+    }
+    return flag;
+}
+
+// Drawable::doAfterHit -> getRawNormal (Surface.cpp:228-231, 68-71; Surface.h:184,197,211);
+// a mesh hit takes the hit triangle's geometric normal.
+__device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
+{
+    const DevObject &o = S.objects[h.obj];
+    if (o.type == RT_OBJ_SPHERE) return norm(p - mk(o.p[0], o.p[1], o.p[2]));
+    if (o.type == RT_OBJ_GROUND) return mk(0, 1, 0);
+    if (o.type == RT_OBJ_WALL_Z) return mk(0, 0, 1);
+    if (o.type == RT_OBJ_WALL_X) return mk(1, 0, 0);
+    const double *tr = S.tris + 9ull * h.prim;
+    return norm(cross(ld3(tr + 3), ld3(tr + 6)));
+}
+__device__ __forceinline__ uint32_t global_prim(const DevScene &S, const Hit &h)
+{
+    const DevObject &o = S.objects[h.obj];
+    return o.type == RT_OBJ_MESH ? o.prim_base + (h.prim - o.tri_base) : o.prim_base;
+}
+
+// Camera::getRay(float s, float t), camera.cpp:24-31
+__device__ __forceinline__ void camera_ray(const rt_camera &c, float s, float t, V3 &e, V3 &d)
+{
+    e = ld3(c.e);
+    V3 lookat = ld3(c.llc) + (ld3(c.u) * (double)s) * c.width + (ld3(c.v) * (double)t) * c.height;
+    d = norm(lookat - e);
+}
+
+__device__ inline void flush_counters(uint64_t *counters, const Counters &c)
+{
+    if (!counters) return;
+    // one atomic per wave and counter: wave-reduce with cross-lane adds first
+    uint64_t v[4] = { c.rays, c.inner, c.leaf, c.prim };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long *)&counters[k], (unsigned long long)x);
+    }
+}
+
+// ------------------------------------------------------------------ closest-hit kernels
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(DevScene S, const rt_ray *rays, uint64_t n, double t0, double t1,
+                                                          uint32_t *prim_id, double *tout, double *normal, uint64_t *counters)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    Counters c = { 0, 0, 0, 0 };
+    if (i < n) {
+        V3 e = ld3(rays[i].e), d = ld3(rays[i].d);
+        Hit h;
+        if (group_hit<RT_BLOCK>(S, e, d, t0, t1, h, stk, c)) {
+            prim_id[i] = global_prim(S, h);
+            if (tout) tout[i] = h.t;
+            if (normal) { V3 nn = hit_normal(S, h, e + d * h.t); normal[3 * i] = nn.x; normal[3 * i + 1] = nn.y; normal[3 * i + 2] = nn.z; }
+        } else {
+            prim_id[i] = RT_MISS;
+            if (tout) tout[i] = RT_INFINITE;
+            if (normal) { normal[3 * i] = 0; normal[3 * i + 1] = 0; normal[3 * i + 2] = 0; }
+        }
+    }
+    flush_counters(counters, c);
+}
+
+// One lane per pixel; a 256-thread block covers a 16 x 16 pixel tile so that the lanes of a
+// wave (16 x 4 pixels) walk neighbouring rays through the same octree nodes.
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(DevScene S, rt_camera cam, int w, int h,
+                                                             uint32_t *prim_id, double *tout, uint64_t *counters)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    const int tiles_x = (w + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
+    Counters c = { 0, 0, 0, 0 };
+    if (x < w && y < h) {
+        V3 e, d;
+        camera_ray(cam, (float)((0.5 + x * 1.0) / w), (float)((0.5 + y * 1.0) / h), e, d);
+        Hit hh;
+        uint64_t pix = (uint64_t)y * w + x;
+        if (group_hit<RT_BLOCK>(S, e, d, 0.0, RT_INFINITE, hh, stk, c)) {
+            prim_id[pix] = global_prim(S, hh);
+            if (tout) tout[pix] = hh.t;
+        } else {
+            prim_id[pix] = RT_MISS;
+            if (tout) tout[pix] = RT_INFINITE;
+        }
+    }
+    flush_counters(counters, c);
+}
+
+// ------------------------------------------------------------------ lights
+// firstIntersection2Sphere, algorithms.h:15-24
+__device__ inline V3 first_intersection_sphere(V3 re, V3 rd, V3 center, double radius, double &length)
+{
+    V3 dir = center - re;
+    double dist = len(dir);
+    double cosv = dot(rd, norm(dir));
+    double coslen = dist * cosv;
+    double sinlen = dist * sqrt(1 - cosv * cosv);
+    double dlen = sqrt(radius * radius - sinlen * sinlen);
+    length = coslen - dlen;
+    return re + rd * length;
+}
+// SphereLight::getPosition (light.cpp:138-190) / FaceLight::getPosition (light.cpp:76-86)
+__device__ inline V3 light_sample(const rt_light &l, V3 ppos, double ru, double rv, V3 &normal, double &p)
+{
+    V3 pos_ = ld3(l.pos);
+    if (l.type == RT_LIGHT_FACE) {
+        V3 pos = pos_ + ((ld3(l.right) * (ru - 0.5)) * l.width + (ld3(l.up) * (rv - 0.5)) * l.height);
+        p = 1.0 / l.width / l.height;
+        normal = ld3(l.normal);
+        return pos;
+    }
+    double radius_ = l.radius;
+    V3 dir = pos_ - ppos;
+    double dl = len(dir);
+    if (fabs(dl - radius_) < RT_ZERO) { p = RT_INFINITE * 1.1; normal = mk(0, 0, 0); return mk(0, 0, 0); }
+    V3 w = dir;
+    V3 u = norm(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w)) * dl;
+    V3 v = norm(cross(w, u)) * dl;
+    double cosmax = sqrt(1 - radius_ * radius_ / dot(dir, dir));
+    if (cosmax >= 1 - RT_ZERO) { p = RT_INFINITE * 1.1; normal = mk(0, 0, 0); return mk(0, 0, 0); }
+    double cos_a = 1 - ru + ru * cosmax;
+    double sin_a = sqrt(1 - cos_a * cos_a);
+    double phi = 2 * RT_PI * rv;
+    V3 lightDir = ((u * cos(phi)) * sin_a + (v * sin(phi)) * sin_a) + w * cos_a;
+    lightDir = norm(lightDir);
+    double length;
+    V3 hitp = first_intersection_sphere(ppos, lightDir, pos_, radius_, length);
+    V3 nl = norm(hitp - pos_);
+    normal = nl;
+    p = dot(nl, -lightDir) / (2 * RT_PI * (1 - cosmax)) / length / length;
+    return hitp;
+}
+// refract, scene.cpp:384-395 (true = total internal reflection)
+__device__ inline bool refract_dir(V3 d, V3 normal, double n, V3 &t)
+{
+    double dn = dot(d, normal);
+    double inSqrt = 1 - (1 - dn * dn) / n / n;
+    if (inSqrt < 0) { t = reflact(d, normal); return true; }
+    t = (d - normal * dn) * (1 / n) - normal * sqrt(inSqrt);
+    t = norm(t);
+    return false;
+}
+
+// ------------------------------------------------------------------ path tracing
+// Scene::rayColor (scene.cpp:194-304) unrolled into a per-lane loop over pending rays.
+//
+// A lane owns one pixel at a time and walks that pixel's sample slice in order, so the
+// per-pixel sum needs no atomics and is added in sample order like Scene::run
+// (scene.cpp:104-112).  Recursion becomes a pending-ray stack in global memory: shading a
+// vertex pushes one record per follow-up ray (bounce rays carry throughput x lobe colour,
+// shadow rays carry the radiance they deliver if unoccluded) and the loop pops the next
+// record, so all lanes of a wave meet at ONE traversal call per iteration whatever kind of
+// ray they carry.  Random numbers are keyed by the ray's position in the path tree, so the
+// order in which pending rays are served does not change any path.
+//
+// Pixels are handed to lanes through a global counter; the lanes of a wave that need work
+// take consecutive indices with one atomic (ballot + popcount), and consecutive indices are
+// the pixels of an 8 x 8 image tile.
+struct Job { V3 e, d; double t0, t1; V3 w; uint64_t key; int32_t jump; int32_t E; int32_t type; };
+
+__device__ __forceinline__ void job_push(const RenderArgs &A, uint64_t lane, uint64_t nlanes, int &sp, const Job &j)
+{
+    if (sp >= A.stack_cap) { *A.overflow = 1; return; }
+    uint64_t *b = A.jobs + ((uint64_t)sp * JOB_FIELDS) * nlanes + lane;
+    b[JOB_EX * nlanes] = __double_as_longlong(j.e.x); b[JOB_EY * nlanes] = __double_as_longlong(j.e.y); b[JOB_EZ * nlanes] = __double_as_longlong(j.e.z);
+    b[JOB_DX * nlanes] = __double_as_longlong(j.d.x); b[JOB_DY * nlanes] = __double_as_longlong(j.d.y); b[JOB_DZ * nlanes] = __double_as_longlong(j.d.z);
+    b[JOB_T1 * nlanes] = __double_as_longlong(j.t1);
+    b[JOB_WX * nlanes] = __double_as_longlong(j.w.x); b[JOB_WY * nlanes] = __double_as_longlong(j.w.y); b[JOB_WZ * nlanes] = __double_as_longlong(j.w.z);
+    b[JOB_KEY * nlanes] = j.key;
+    b[JOB_META * nlanes] = (uint64_t)(uint32_t)j.jump | ((uint64_t)(j.E & 1) << 32) | ((uint64_t)(j.type & 1) << 33);
+    sp++;
+}
+__device__ __forceinline__ void job_pop(const RenderArgs &A, uint64_t lane, uint64_t nlanes, int &sp, Job &j)
+{
+    sp--;
+    const uint64_t *b = A.jobs + ((uint64_t)sp * JOB_FIELDS) * nlanes + lane;
+    j.e = mk(__longlong_as_double(b[JOB_EX * nlanes]), __longlong_as_double(b[JOB_EY * nlanes]), __longlong_as_double(b[JOB_EZ * nlanes]));
+    j.d = mk(__longlong_as_double(b[JOB_DX * nlanes]), __longlong_as_double(b[JOB_DY * nlanes]), __longlong_as_double(b[JOB_DZ * nlanes]));
+    j.t0 = RT_ZERO;
+    j.t1 = __longlong_as_double(b[JOB_T1 * nlanes]);
+    j.w = mk(__longlong_as_double(b[JOB_WX * nlanes]), __longlong_as_double(b[JOB_WY * nlanes]), __longlong_as_double(b[JOB_WZ * nlanes]));
+    j.key = b[JOB_KEY * nlanes];
+    uint64_t meta = b[JOB_META * nlanes];
+    j.jump = (int32_t)(uint32_t)meta;
+    j.E = (int32_t)((meta >> 32) & 1);
+    j.type = (int32_t)((meta >> 33) & 1);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_render(DevScene S, RenderArgs A)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    const uint64_t nlanes = (uint64_t)gridDim.x * RT_BLOCK;
+    const uint64_t lane = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t lane_in_wave = threadIdx.x & 63;
+
+    // work items: batch mode = rays; camera mode = pixels enumerated tile by tile (8 x 8)
+    const uint32_t tiles_x = A.batch ? 0u : (uint32_t)((A.width + 7) >> 3);
+    const uint32_t tiles_y = A.batch ? 0u : (uint32_t)((A.height + 7) >> 3);
+    const uint64_t total = A.batch ? A.nrays : (uint64_t)tiles_x * tiles_y * 64ull;
+    const uint32_t tab_n = A.batch ? 1u : (uint32_t)A.n, tab_m = A.batch ? 1u : (uint32_t)A.m;
+
+    Counters c = { 0, 0, 0, 0 };
+    V3 psum = mk(0, 0, 0);
+    uint64_t pix = 0;          // pixel index (row-major) or ray index: the sampler's pixel key
+    int px = 0, py = 0;
+    int k = 0, k_end = 0;      // current / one-past-last sample index of the owned pixel
+    bool own = false;          // lane owns a work item
+    bool exhausted = false;    // the global counter ran out
+    int sp = 0;
+    Job job;
+    bool have = false;
+
+    for (;;) {
+        // ---- phase A: give every lane without a ray its next ray
+        if (!have) {
+            if (sp > 0) {
+                job_pop(A, lane, nlanes, sp, job);
+                have = true;
+            } else {
+                if (own) {
+                    k++;
+                    if (k >= k_end) {                        // item finished: write its sum
+                        double *o = A.out + 3 * pix;
+                        if (A.batch) { o[0] = psum.x; o[1] = psum.y; o[2] = psum.z; }
+                        else { o[0] += psum.x; o[1] += psum.y; o[2] += psum.z; }
+                        own = false;
+                    }
+                }
+                if (!own && !exhausted) {
+                    // wave-aggregated fetch: lanes that need work take consecutive indices
+                    const unsigned long long need = __ballot(1);
+                    const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
+                    const uint32_t cntw = (uint32_t)__popcll(need);
+                    uint32_t base = 0;
+                    if (lane_in_wave == leader) base = atomicAdd(A.next_work, cntw);
+                    base = __shfl(base, (int)leader, 64);
+                    const uint64_t idx = (uint64_t)base + (uint64_t)__popcll(need & ((1ull << lane_in_wave) - 1ull));
+                    if (idx >= total) {
+                        exhausted = true;
+                    } else if (A.batch) {
+                        pix = idx; own = true; k = 0; k_end = 1; psum = mk(0, 0, 0);
+                    } else {
+                        const uint32_t tile = (uint32_t)(idx >> 6), l = (uint32_t)(idx & 63);
+                        px = (int)((tile % tiles_x) * 8 + (l & 7));
+                        py = (int)((tile / tiles_x) * 8 + (l >> 3));
+                        if (px < A.width && py < A.height && A.sample_begin < A.sample_end) {
+                            pix = (uint64_t)py * A.width + px;
+                            own = true; k = A.sample_begin; k_end = A.sample_end; psum = mk(0, 0, 0);
+                        }
+                    }
+                }
+                if (own) {                                   // first ray of sample k
+                    if (A.batch) {
+                        job.e = ld3(A.rays[pix].e); job.d = ld3(A.rays[pix].d);
+                        job.t0 = A.t0; job.t1 = A.t1; job.jump = A.jumptime;
+                    } else {
+                        double jx, jy;                         // Scene::run, scene.cpp:105-108
+                        jitter_pair(A.seed, pix, 0, (uint32_t)k, tab_n, tab_m, jx, jy);
+                        camera_ray(A.cam, (float)((jx + px * 1.0) / A.width), (float)((jy + py * 1.0) / A.height), job.e, job.d);
+                        job.t0 = 0; job.t1 = RT_INFINITE; job.jump = 0;
+                    }
+                    job.w = mk(1, 1, 1); job.E = 1; job.type = JOB_RADIANCE;
+                    job.key = path_root_key(A.seed, pix, (uint32_t)k);
+                    have = true;
+                }
+            }
+        }
+        if (__ballot(have || own || sp > 0 || !exhausted) == 0ull) break;
+
+        // ---- depth cut-off (scene.cpp:196-198) happens before any intersection work
+        int jt = 0;
+        if (have && job.type == JOB_RADIANCE) {
+            jt = job.jump + 1;
+            if (jt > A.max_jump) {
+                psum = psum + had(job.w, ld3(S.background));
+                have = false;
+            }
+        }
+
+        // ---- phase B: one closest-hit query per lane that carries a ray
+        Hit h;
+        bool hit = false;
+        if (have) hit = group_hit<RT_BLOCK>(S, job.e, job.d, job.t0, job.t1, h, stk, c);
+
+        // ---- phase C: consume the result
+        if (have) {
+            have = false;
+            if (job.type == JOB_SHADOW) {
+                if (!hit) psum = psum + job.w;                // scene.cpp:236-238
+            } else if (!hit) {
+                psum = psum + had(job.w, ld3(S.background));   // scene.cpp:378-380
+            } else {
+                const rt_material &mat = S.materials[S.objects[h.obj].material];
+                const V3 p = job.e + job.d * h.t;
+                const V3 normal = hit_normal(S, h, p);
+                const V3 emission = ld3(mat.emission), mcolor = ld3(mat.color);
+                const double Ed = (double)job.E;
+                const V3 W = job.w;
+                V3 cc = mcolor;
+                bool alive = true;
+                if (jt > A.rus_jump) {                         // Russian roulette, scene.cpp:208-212
+                    double pr = (cc.x > cc.y && cc.x > cc.z) ? cc.x : (cc.y > cc.z ? cc.y : cc.z);
+                    if (draw(job.key, SLOT_RR) < pr) cc = cc * (1 / pr);
+                    else { psum = psum + had(W, emission * Ed); alive = false; }
+                }
+                if (alive && (mat.type & RT_MAT_NORMAL)) {      // scene.cpp:213-248
+                    double r1 = RT_PI * 2 * draw(job.key, SLOT_DIFF1);
+                    double r2 = draw(job.key, SLOT_DIFF2), r2s = sqrt(r2);
+                    V3 w = normal;
+                    if (A.face_forward && dot(w, job.d) > 0) w = -w;
+                    V3 u = norm(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
+                    V3 v = cross(w, u);
+                    V3 dn = norm(((u * cos(r1)) * r2s + (v * sin(r1)) * r2s) + w * sqrt(1 - r2));
+                    psum = psum + had(W, emission * Ed);
+                    Job nj;
+                    nj.e = p; nj.d = dn; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.w = had(W, mcolor);
+                    nj.key = hash2(job.key, BR_DIFFUSE); nj.jump = jt + 1; nj.E = 0; nj.type = JOB_RADIANCE;
+                    job_push(A, lane, nlanes, sp, nj);
+                    const V3 wn = norm(w);
+                    for (int li = 0; li < S.nlights; li++) {     // next-event estimation, scene.cpp:223-246
+                        const rt_light &L = S.lights[li];
+                        double lu, lv;
+                        jitter_pair(A.seed, pix, 1u + (uint32_t)li, (uint32_t)k, tab_n, tab_m, lu, lv);
+                        V3 nl; double pr;
+                        V3 ppos = job.d * h.t + job.e;           // light.cpp:143
+                        V3 lightpos = light_sample(L, ppos, lu, lv, nl, pr);
+                        if (pr > RT_INFINITE) continue;
+                        double dist = len(lightpos - p);
+                        V3 ldir = norm(lightpos - p);
+                        double dt = dot(nl, -ldir);
+                        double dt2 = dot(wn, ldir);
+                        if (dt < 0 || dt2 < 0) continue;
+                        V3 ld = ((ld3(L.diffuse) * dt) * dt2) * (1 / pr / dist / dist);
+                        Job sj;
+                        sj.e = p; sj.d = ldir; sj.t0 = RT_ZERO; sj.t1 = dist - RT_ZERO; sj.w = had(W, had(cc, ld));
+                        sj.key = 0; sj.jump = 0; sj.E = 0; sj.type = JOB_SHADOW;
+                        job_push(A, lane, nlanes, sp, sj);
+                    }
+                }
+                if (alive && (mat.type & RT_MAT_SPECULAR)) {    // scene.cpp:249-266
+                    V3 md = job.d - (normal * dot(normal, job.d)) * 2;
+                    if (mat.blur >= RT_ZERO) {
+                        V3 vec = mk(0, 0, 1);
+                        if (iszero(cross(vec, md))) vec = mk(0, 1, 0);
+                        V3 u = norm(cross(vec, md));
+                        V3 v = norm(cross(md, u));
+                        double x, y;
+                        uint32_t a = 0;
+                        do {                                     // randFromDisk, algorithms.h:30-35
+                            x = (draw(job.key, SLOT_DISK + 2 * a) - 0.5) * 2;
+                            y = (draw(job.key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
+                            a++;
+                        } while (x * x + y * y >= 1.0);
+                        x *= mat.blur; y *= mat.blur;
+                        md = (md + u * x) + v * y;
+                    }
+                    psum = psum + had(W, emission * Ed);
+                    Job nj;
+                    nj.e = p; nj.d = md; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.w = had(W, mcolor);
+                    nj.key = hash2(job.key, BR_SPECULAR); nj.jump = jt; nj.E = 1; nj.type = JOB_RADIANCE;
+                    job_push(A, lane, nlanes, sp, nj);
+                }
+                if (alive && (mat.type & RT_MAT_TRANSPARENT)) { // scene.cpp:267-303
+                    V3 kk = mk(1, 1, 1);
+                    double cosv = 0;
+                    V3 r = reflact(job.d, normal);
+                    V3 rd = mk(0, 0, 0);
+                    bool tir = false;
+                    if (dot(normal, job.d) > 0) {
+                        kk.x = exp(-mat.atten[0] * h.t);
+                        kk.y = exp(-mat.atten[1] * h.t);
+                        kk.z = exp(-mat.atten[2] * h.t);
+                        if (refract_dir(job.d, -normal, 1 / mat.nr, rd)) {
+                            tir = true;
+                            psum = psum + had(W, emission * Ed);
+                            Job nj;
+                            nj.e = p; nj.d = r; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.w = had(W, kk);
+                            nj.key = hash2(job.key, BR_REFLECT); nj.jump = jt; nj.E = 1; nj.type = JOB_RADIANCE;
+                            job_push(A, lane, nlanes, sp, nj);
+                        } else {
+                            cosv = dot(rd, normal);
+                        }
+                    } else {
+                        cosv = dot(-job.d, normal);
+                        refract_dir(job.d, normal, mat.nr, rd);
+                    }
+                    if (!tir) {
+                        double n = mat.nr;
+                        double R0 = (n - 1) * (n - 1) / (n + 1) / (n + 1);
+                        double R = R0 + (1 - R0) * pow(1 - cosv, 5.0);
+                        Job nj;
+                        nj.e = p; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.jump = jt; nj.E = 1; nj.type = JOB_RADIANCE;
+                        nj.d = rd; nj.w = had(W, kk * (1 - R)); nj.key = hash2(job.key, BR_REFRACT);
+                        job_push(A, lane, nlanes, sp, nj);
+                        nj.d = r; nj.w = had(W, kk * R); nj.key = hash2(job.key, BR_REFLECT);
+                        job_push(A, lane, nlanes, sp, nj);
+                    }
+                }
+            }
+        }
+    }
+    flush_counters(A.counters, c);
+}
+
+// colorArray_ -> bytes: average, regularize (types.h:167-177), int(c*255) as B,G,R (scene.cpp:183-185)
+__global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, uint8_t *bgr)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    double c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double v = sum[3 * i + k] * inv;
+        if (v > 1.0) v = 1.0; else if (v < 0) v = 0;
+        c[k] = v;
+    }
+    bgr[3 * i + 2] = (uint8_t)(int)(c[0] * 255);
+    bgr[3 * i + 1] = (uint8_t)(int)(c[1] * 255);
+    bgr[3 * i + 0] = (uint8_t)(int)(c[2] * 255);
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t launch_trace_rays(const DevScene &S, const rt_ray *rays, uint64_t n, double t0, double t1,
+                             uint32_t *prim_id, double *t, double *normal, uint64_t *counters, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
+    hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, st, S, rays, n, t0, t1, prim_id, t, normal, counters);
+    return hipGetLastError();
+}
+hipError_t launch_trace_primary(const DevScene &S, const rt_camera &cam, int w, int h, uint32_t *prim_id, double *t,
+                                uint64_t *counters, hipStream_t st)
+{
+    unsigned blocks = (unsigned)(((w + 15) >> 4) * ((h + 15) >> 4));
+    hipLaunchKernelGGL(k_trace_primary, dim3(blocks), dim3(RT_BLOCK), 0, st, S, cam, w, h, prim_id, t, counters);
+    return hipGetLastError();
+}
+int render_blocks_per_cu()
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render, RT_BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
+    if (nb > 4) nb = 4;
+    return nb;
+}
+hipError_t launch_render(const DevScene &S, const RenderArgs &A, unsigned blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RT_BLOCK), 0, st, S, A);
+    return hipGetLastError();
+}
+hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st)
+{
+    if (npix == 0) return hipSuccess;
+    double inv = 1.0 / spp;                                   // scene.cpp:112
+    hipLaunchKernelGGL(k_resolve_bgr8, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, sum, npix, inv, bgr);
+    return hipGetLastError();
+}
+
+} // namespace rt

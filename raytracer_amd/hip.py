@@ -1,0 +1,188 @@
+"""ctypes binding of librt_hip.so (the C ABI declared in include/rt_hip.h).
+
+There is no fallback: if the shared library is missing or no HIP device is usable, every
+call raises.  torch is imported first (when importable) only so that this process ends up
+with ONE HIP runtime: the library and torch both resolve the soname libamdhip64.so.7 and
+the first one loaded wins; loading them in the other order would give torch tensors and
+this library different runtimes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .desc import CameraC, RAY_DT, RenderParamsC, SceneDescC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+
+EXPORTS = (
+    "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
+    "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
+    "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
+    "rt_render_host", "rt_scene_check", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
+)
+
+_lib = None
+_vp, _u64, _dbl, _int = C.c_void_p, C.c_uint64, C.c_double, C.c_int
+_dp = C.POINTER(C.c_double)
+
+
+def lib():
+    """Load librt_hip.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    try:  # see module docstring
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_set_device.argtypes = [_int]
+    L.rt_scene_create.argtypes = [C.POINTER(SceneDescC), C.POINTER(_vp)]
+    L.rt_scene_destroy.argtypes = [_vp]
+    L.rt_scene_octree_stats.argtypes = [_vp, _int, C.POINTER(_u64)]
+    L.rt_camera_init.argtypes = [_dp, _dp, _dp, _dbl, _dbl, C.POINTER(CameraC)]
+    L.rt_trace_rays.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]
+    L.rt_trace_rays_host.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _vp, _vp, _vp, _vp]
+    L.rt_trace_primary.argtypes = [_vp, C.POINTER(CameraC), _int, _int, _vp, _vp, _vp, _vp]
+    L.rt_trace_primary_host.argtypes = [_vp, C.POINTER(CameraC), _int, _int, _vp, _vp, _vp]
+    L.rt_ray_color.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _int, C.POINTER(RenderParamsC), _vp, _vp, _vp]
+    L.rt_ray_color_host.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _int, C.POINTER(RenderParamsC), _vp, _vp]
+    L.rt_render.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _vp, _vp, _vp]
+    L.rt_render_host.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _vp, _vp]
+    L.rt_scene_check.argtypes = [_vp, _vp]
+    L.rt_resolve_bgr8.argtypes = [_vp, _int, _int, _int, _vp, _vp]
+    L.rt_resolve_bgr8_host.argtypes = [_vp, _int, _int, _int, _vp]
+    L.rt_save_bmp.argtypes = [_vp, _int, _int, C.c_char_p]
+    _lib = L
+    return L
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RtError(f"{what} failed ({rc}): {lib().rt_last_error().decode(errors='replace')}")
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _d3(x):
+    return (C.c_double * 3)(*[float(v) for v in x])
+
+
+def device_count():
+    n = lib().rt_device_count()
+    if n < 0:
+        raise RtError("rt_device_count: " + lib().rt_last_error().decode())
+    return n
+
+
+def set_device(i):
+    _chk(lib().rt_set_device(int(i)), "rt_set_device")
+
+
+def camera_init(look_from, look_at, vup, vfov, aspect):
+    """Camera(lookFrom, lookAt, vup, vfov, aspect) -- camera.cpp:5-8,37-48."""
+    cam = CameraC()
+    _chk(lib().rt_camera_init(_d3(look_from), _d3(look_at), _d3(vup), float(vfov), float(aspect), C.byref(cam)),
+         "rt_camera_init")
+    return cam
+
+
+def save_bmp(bgr, filename):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    _chk(lib().rt_save_bmp(_p(bgr), w, h, os.fsencode(filename)), "rt_save_bmp")
+
+
+def resolve_bgr8_host(radiance_sum, spp):
+    a = np.ascontiguousarray(radiance_sum, np.float64)
+    h, w, _ = a.shape
+    out = np.empty((h, w, 3), np.uint8)
+    _chk(lib().rt_resolve_bgr8_host(_p(a), w, h, int(spp), _p(out)), "rt_resolve_bgr8_host")
+    return out
+
+
+class HipScene:
+    """Device-resident scene (octrees flattened and uploaded once)."""
+
+    def __init__(self, desc):
+        self.desc = desc
+        d, keep = desc.to_c()
+        h = _vp()
+        _chk(lib().rt_scene_create(C.byref(d), C.byref(h)), "rt_scene_create")
+        del keep
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def octree_stats(self, mesh=0):
+        out = (_u64 * 6)()
+        _chk(lib().rt_scene_octree_stats(self._h, mesh, out), "rt_scene_octree_stats")
+        return dict(zip(("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost"), [int(x) for x in out]))
+
+    # ---- host-buffer entry points (numpy in / numpy out)
+    def trace_rays(self, rays, t0=0.0, t1=1e10):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        n = len(rays)
+        prim = np.empty(n, np.uint32); t = np.empty(n, np.float64); nrm = np.empty((n, 3), np.float64)
+        cnt = np.zeros(4, np.uint64)
+        _chk(lib().rt_trace_rays_host(self._h, _p(rays), n, t0, t1, _p(prim), _p(t), _p(nrm), _p(cnt)), "rt_trace_rays_host")
+        return prim, t, nrm, cnt
+
+    def trace_primary(self, cam, w, h):
+        prim = np.empty((h, w), np.uint32); t = np.empty((h, w), np.float64)
+        cnt = np.zeros(4, np.uint64)
+        _chk(lib().rt_trace_primary_host(self._h, C.byref(cam), w, h, _p(prim), _p(t), _p(cnt)), "rt_trace_primary_host")
+        return prim, t, cnt
+
+    def ray_color(self, rays, params, t0=0.0, t1=1e10, jumptime=0):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DT)
+        out = np.zeros((len(rays), 3), np.float64)
+        cnt = np.zeros(4, np.uint64)
+        _chk(lib().rt_ray_color_host(self._h, _p(rays), len(rays), t0, t1, jumptime, C.byref(params), _p(out), _p(cnt)),
+             "rt_ray_color_host")
+        return out, cnt
+
+    def render(self, cam, params, radiance_sum=None):
+        if radiance_sum is None:
+            radiance_sum = np.zeros((params.height, params.width, 3), np.float64)
+        assert radiance_sum.shape == (params.height, params.width, 3) and radiance_sum.dtype == np.float64
+        cnt = np.zeros(4, np.uint64)
+        _chk(lib().rt_render_host(self._h, C.byref(cam), C.byref(params), _p(radiance_sum), _p(cnt)), "rt_render_host")
+        return radiance_sum, cnt
+
+    # ---- device-pointer entry points (raw addresses, e.g. torch tensors' data_ptr())
+    def render_dev(self, cam, params, radiance_sum_ptr, counters_ptr=0, stream=0):
+        _chk(lib().rt_render(self._h, C.byref(cam), C.byref(params), radiance_sum_ptr, counters_ptr or None, stream or None),
+             "rt_render")
+
+    def trace_primary_dev(self, cam, w, h, prim_ptr, t_ptr=0, counters_ptr=0, stream=0):
+        _chk(lib().rt_trace_primary(self._h, C.byref(cam), w, h, prim_ptr, t_ptr or None, counters_ptr or None, stream or None),
+             "rt_trace_primary")
+
+    def check(self, stream=0):
+        _chk(lib().rt_scene_check(self._h, stream or None), "rt_scene_check")
+
+
+def resolve_bgr8_dev(radiance_sum_ptr, w, h, spp, bgr_ptr, stream=0):
+    _chk(lib().rt_resolve_bgr8(radiance_sum_ptr, w, h, int(spp), bgr_ptr, stream or None), "rt_resolve_bgr8")
