@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,7 +32,7 @@ template <class T>
 hipError_t upload(const std::vector<T> &v, void **dptr)
 {
     size_t bytes = v.size() * sizeof(T);
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    hipError_t e = hipMalloc(dptr, bytes > 256 ? bytes : 256);
     if (e != hipSuccess) return e;
     if (bytes) e = hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice);
     return e;
@@ -47,11 +48,13 @@ struct rt_scene {
     std::vector<MeshInfo> meshes;
     std::vector<rt_material> materials;
     int nlights = 0;
+    int max_push = 1;             // most follow-up rays one shaded hit can append
     // path-tracing workspace (grown on demand, reused by later calls)
-    uint64_t *d_jobs = nullptr;
-    size_t jobs_bytes = 0;
-    uint32_t *d_ctrl = nullptr;   // [0] work counter, [1] overflow flag
-    int blocks_per_cu = 0;
+    RayStack stack[2] = {};
+    void *stack_mem[2] = {nullptr, nullptr};
+    uint32_t *d_ctrl = nullptr;   // [0] rays appended by the running shade kernel
+    uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0]
+    int failed = 0;               // a render ran out of ray-stack space
 };
 
 extern "C" {
@@ -107,8 +110,9 @@ int rt_scene_destroy(rt_scene *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    if (s->d_jobs) (void)hipFree(s->d_jobs);
+    for (int k = 0; k < 2; k++) if (s->stack_mem[k]) (void)hipFree(s->stack_mem[k]);
     if (s->d_ctrl) (void)hipFree(s->d_ctrl);
+    if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
     delete s;
     return 0;
 }
@@ -206,6 +210,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     };
     up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(obj_index, &p_idx); up(tris, &p_tris);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
     if (e != hipSuccess) { rt_scene_destroy(s); return fail_hip("scene upload", e); }
     s->dev.objects = (const DevObject *)p_obj;
     s->dev.materials = (const rt_material *)p_mat;
@@ -219,6 +224,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->meshes = infos;
     s->materials = mats;
     s->nlights = (int)d->nlights;
+    for (const rt_material &m : mats) {
+        int push = ((m.type & RT_MAT_NORMAL) ? 1 + s->nlights : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 2 : 0);
+        if (push > s->max_push) s->max_push = push;
+    }
     *out = s;
     return 0;
 }
@@ -252,49 +261,84 @@ int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *
     return 0;
 }
 
-// Upper bound on the pending rays one lane can hold: a vertex pushes one record per bounce
-// ray and per light; records left behind when the lane follows a bounce ray stay until that
-// whole subtree is done, and paths are at most max_jump vertices deep.
-static int pending_capacity(const rt_scene *s, int max_jump)
+// ---------------------------------------------------------------- wavefront driver
+// Two ray stacks alternate as source and destination.  Each round pops a chunk of at most
+// `target` rays from the top of the source (the most recently appended, i.e. deepest, rays),
+// traces and shades it, and appends the follow-up rays to the other stack, which becomes the
+// next source.  New camera rays are added while the source holds fewer than `target` rays,
+// which keeps the trace kernel's grid full until every sample has been issued ("path
+// regeneration").  One 4-byte read-back per round tells the host how many rays were appended.
+static uint64_t env_u64(const char *name, uint64_t dflt)
 {
-    int max_left = 0, max_push = 1;
-    for (const rt_material &m : s->materials) {
-        int lobes = ((m.type & RT_MAT_NORMAL) ? 1 : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 1 : 0);
-        int push = ((m.type & RT_MAT_NORMAL) ? 1 + s->nlights : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 2 : 0);
-        int left;
-        if (lobes <= 1 && !(m.type & RT_MAT_TRANSPARENT)) left = 0;   // shadow rays are served before the bounce ray
-        else left = push - 1;
-        if (left > max_left) max_left = left;
-        if (push > max_push) max_push = push;
-    }
-    return max_left * (max_jump + 1) + max_push + 1;
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    unsigned long long x = std::strtoull(v, &end, 10);
+    return (end && *end == 0 && x > 0) ? (uint64_t)x : dflt;
 }
 
-static int render_common(rt_scene *s, RenderArgs &A, uint64_t total_items, hipStream_t st)
+static int ensure_stacks(rt_scene *s, uint64_t cap, hipStream_t st)
 {
-    if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
-    if (!s->blocks_per_cu) s->blocks_per_cu = render_blocks_per_cu();
-    uint64_t blocks = (uint64_t)(s->num_cu > 0 ? s->num_cu : 256) * s->blocks_per_cu;
-    uint64_t need_blocks = (total_items + RT_BLOCK - 1) / RT_BLOCK;
-    if (need_blocks < blocks) blocks = need_blocks;
-    if (blocks == 0) return 0;
-    const uint64_t nlanes = blocks * RT_BLOCK;
-    A.stack_cap = pending_capacity(s, A.max_jump);
-    size_t bytes = (size_t)A.stack_cap * JOB_FIELDS * sizeof(uint64_t) * nlanes;
-    if (bytes > s->jobs_bytes) {
-        if (s->d_jobs) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(s->d_jobs)); s->d_jobs = nullptr; s->jobs_bytes = 0; }
-        HIP_TRY(hipMalloc((void **)&s->d_jobs, bytes));
-        s->jobs_bytes = bytes;
+    if (s->stack[0].cap >= cap) return 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 2; k++) {
+        if (s->stack_mem[k]) { HIP_TRY(hipFree(s->stack_mem[k])); s->stack_mem[k] = nullptr; s->stack[k].cap = 0; }
+        const size_t words = (size_t)cap * (RAY_FIELDS + 2);
+        HIP_TRY(hipMalloc(&s->stack_mem[k], words * sizeof(uint64_t)));
+        uint64_t *base = (uint64_t *)s->stack_mem[k];
+        s->stack[k].f = base;
+        s->stack[k].hit_t = (double *)(base + (size_t)cap * RAY_FIELDS);
+        s->stack[k].hit_id = base + (size_t)cap * (RAY_FIELDS + 1);
+        s->stack[k].cap = cap;
     }
-    A.jobs = s->d_jobs;
-    A.next_work = s->d_ctrl;
-    A.overflow = s->d_ctrl + 1;
-    HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 8, st));
-    HIP_TRY(launch_render(s->dev, A, (unsigned)blocks, st));
     return 0;
 }
 
-static int fill_args(const rt_render_params *p, RenderArgs &A, bool batch)
+static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStream_t st)
+{
+    if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
+    if (total_items == 0) return 0;
+    const uint64_t max_push = (uint64_t)s->max_push;
+    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", 4u << 20);        // rays per round
+    if (target > total_items * max_push) target = total_items * max_push;
+    if (target < RT_BLOCK) target = RT_BLOCK;
+    const uint64_t cap = target * (max_push + 3);
+    if (cap >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
+    if (int rc = ensure_stacks(s, cap, st)) return rc;
+
+    uint64_t count[2] = {0, 0};
+    uint64_t issued = 0;
+    int src = 0;
+    for (;;) {
+        if (count[src] == 0 && count[src ^ 1] != 0) src ^= 1;
+        // top up with first rays
+        if (issued < total_items && count[src] < target) {
+            uint64_t m = target - count[src];
+            if (m > total_items - issued) m = total_items - issued;
+            HIP_TRY(launch_generate(A, s->stack[src], count[src], issued, (uint32_t)m, st));
+            count[src] += m;
+            issued += m;
+        }
+        if (count[src] == 0) break;
+        const int dst = src ^ 1;
+        uint64_t c = count[src] < target ? count[src] : target;
+        const uint64_t room = (cap - count[dst]) / max_push;
+        if (c > room) c = room;
+        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+        const uint64_t base = count[src] - c;
+        HIP_TRY(launch_trace(s->dev, A, s->stack[src], base, (uint32_t)c, st));
+        HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 4, st));
+        HIP_TRY(launch_shade(s->dev, A, s->stack[src], base, (uint32_t)c, s->stack[dst], count[dst], s->d_ctrl, st));
+        HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->d_ctrl, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        count[src] -= c;
+        count[dst] += s->h_ctrl[0];
+        if (s->h_ctrl[0]) src = dst;
+    }
+    return 0;
+}
+
+static int fill_args(const rt_render_params *p, WaveArgs &A, bool batch)
 {
     if (!p) return fail("render: null params");
     std::memset(&A, 0, sizeof A);
@@ -314,38 +358,38 @@ int rt_ray_color(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double 
     if (!s) return fail("rt_ray_color: null scene");
     if (n && (!rays || !out)) return fail("rt_ray_color: null buffer");
     if (n >= 0xFFFFFFFFull) return fail("rt_ray_color: batch too large");
-    if (jumptime < 0) return fail("rt_ray_color: negative jumptime");
-    RenderArgs A;
+    if (jumptime < 0 || jumptime > 60) return fail("rt_ray_color: jumptime must be in [0,60]");
+    WaveArgs A;
     if (int rc = fill_args(p, A, true)) return rc;
     HIP_TRY(hipSetDevice(s->device));
-    A.batch = 1; A.rays = rays; A.nrays = n; A.t0 = t0; A.t1 = t1; A.jumptime = jumptime;
+    A.batch = 1; A.rays = rays; A.t0 = t0; A.t1 = t1; A.jumptime = jumptime;
     A.out = out; A.counters = counters;
-    return render_common(s, A, n, (hipStream_t)stream);
+    if (n) HIP_TRY(hipMemsetAsync(out, 0, n * 3 * sizeof(double), (hipStream_t)stream));
+    return run_wavefront(s, A, n, (hipStream_t)stream);
 }
 
 int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *radiance_sum, uint64_t *counters, void *stream)
 {
     if (!s || !cam) return fail("rt_render: null argument");
     if (!radiance_sum) return fail("rt_render: null buffer");
-    RenderArgs A;
+    WaveArgs A;
     if (int rc = fill_args(p, A, false)) return rc;
     HIP_TRY(hipSetDevice(s->device));
     A.cam = *cam; A.out = radiance_sum; A.counters = counters;
-    uint64_t items = (uint64_t)((A.width + 7) >> 3) * (uint64_t)((A.height + 7) >> 3) * 64ull;
-    if (items >= 0xFFFFFFFFull) return fail("rt_render: image too large");
-    return render_common(s, A, items, (hipStream_t)stream);
+    A.t0 = 0; A.t1 = 1e10; A.jumptime = 0;                       // rayColor(ray, 0, INFINITE), scene.cpp:110
+    const uint64_t npix = (uint64_t)A.width * (uint64_t)A.height;
+    if (npix >= 0xFFFFFFFFull) return fail("rt_render: image too large");
+    return run_wavefront(s, A, npix * (uint64_t)(A.sample_end - A.sample_begin), (hipStream_t)stream);
 }
 
-/* Reports whether any path-tracing launch on this scene ran out of pending-ray slots
- * (cannot happen while pending_capacity() is an upper bound).  Synchronises `stream`. */
+/* Synchronises `stream` and reports whether an earlier path-tracing call on this scene
+ * failed for lack of ray-stack space. */
 int rt_scene_check(rt_scene *s, void *stream)
 {
     if (!s) return fail("rt_scene_check: null scene");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    uint32_t ctrl[2] = {0, 0};
-    HIP_TRY(hipMemcpy(ctrl, s->d_ctrl, 8, hipMemcpyDeviceToHost));
-    if (ctrl[1]) return fail("path tracing ran out of pending-ray slots");
+    if (s->failed) return fail("an earlier path-tracing call ran out of ray-stack space");
     return 0;
 }
 

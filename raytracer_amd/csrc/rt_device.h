@@ -34,12 +34,28 @@ struct DevScene {
 enum { RT_STACK_LEVELS = 16 };     // octree depth <= 15 -> at most 16 open nodes
 enum { RT_BLOCK = 256 };
 
-// Pending-ray record fields (one 8-byte word each), stored field-major and lane-interleaved:
-// word(entry, field, lane) = ((entry * JOB_FIELDS + field) * nlanes + lane)
-enum { JOB_EX = 0, JOB_EY, JOB_EZ, JOB_DX, JOB_DY, JOB_DZ, JOB_T1, JOB_WX, JOB_WY, JOB_WZ, JOB_KEY, JOB_META, JOB_FIELDS };
-enum { JOB_RADIANCE = 0, JOB_SHADOW = 1 };
+// ---------------------------------------------------------------------------------------------
+// Path tracing runs as a wavefront pipeline over pools of pending rays ("ray stacks"):
+//   k_generate  appends camera rays for the next (pixel, sample) work items,
+//   k_trace     finds the closest hit of every ray of the chunk on top of the source stack,
+//   k_shade     consumes the hits: adds radiance to the pixel sums and appends the follow-up
+//               rays (bounce rays and shadow rays) to the destination stack.
+// A ray record is 12 eight-byte words stored field-major (one array per field), so that the
+// lanes of a wave read and write consecutive addresses.
+enum { RAY_EX = 0, RAY_EY, RAY_EZ, RAY_DX, RAY_DY, RAY_DZ, RAY_T1, RAY_WX, RAY_WY, RAY_WZ, RAY_KEY, RAY_META, RAY_FIELDS };
+enum { RAY_RADIANCE = 0, RAY_SHADOW = 1 };
+// RAY_META: bits 0-31 pixel (or ray index in batch mode), 32-55 sample index, 56-61 depth
+// (the jumpTime argument of rayColor), 62 E flag, 63 kind (RAY_SHADOW).  A ray whose depth is
+// the call's initial depth is a first ray and uses the caller's [t0,t1] window.
 
-struct RenderArgs {
+struct RayStack {
+    uint64_t *f;        // RAY_FIELDS arrays of `cap` words each: field k at f + k*cap
+    double   *hit_t;    // cap
+    uint64_t *hit_id;   // cap: obj << 32 | prim, or ~0 for a miss
+    uint64_t  cap;
+};
+
+struct WaveArgs {
     rt_camera cam;
     int32_t  width, height;
     int32_t  n, m;
@@ -47,17 +63,13 @@ struct RenderArgs {
     int32_t  max_jump, rus_jump;
     uint64_t seed;
     int32_t  face_forward;
-    int32_t  batch;            // 1: rays come from `rays` (getRayColor hook), 0: camera
+    int32_t  batch;            // 1: first rays come from `rays` (getRayColor hook), 0: camera
     const rt_ray *rays;        // batch mode
-    uint64_t nrays;
-    double   t0, t1;           // batch mode window of the first ray
-    int32_t  jumptime;         // batch mode initial depth
-    int32_t  stack_cap;        // pending-ray entries per lane
-    uint64_t *jobs;            // pending-ray storage
-    uint32_t *next_work;       // global work counter
-    double   *out;             // camera: radiance_sum [H][W][3] (+=) ; batch: out [n][3] (=)
-    uint64_t *counters;        // nullable
-    uint32_t *overflow;        // set to 1 if a lane ran out of pending-ray slots
+    double   t0, t1;           // window of first rays
+    int32_t  jumptime;         // initial depth of first rays
+    int32_t  pad;
+    double   *out;             // camera: radiance_sum [H][W][3] ; batch: out [n][3]   (atomic +=)
+    uint64_t *counters;        // nullable: {rays, inner visits, leaf visits, primitive tests}
 };
 
 } // namespace rt

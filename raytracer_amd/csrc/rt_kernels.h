@@ -10,9 +10,11 @@ hipError_t launch_trace_rays(const DevScene &S, const rt_ray *rays, uint64_t n, 
                              uint32_t *prim_id, double *t, double *normal, uint64_t *counters, hipStream_t st);
 hipError_t launch_trace_primary(const DevScene &S, const rt_camera &cam, int w, int h, uint32_t *prim_id, double *t,
                                 uint64_t *counters, hipStream_t st);
-// resident 256-thread blocks per CU of the path-tracing kernel (capped), for sizing its grid
-int render_blocks_per_cu();
-hipError_t launch_render(const DevScene &S, const RenderArgs &A, unsigned blocks, hipStream_t st);
+// wavefront path-tracing stages (see rt_device.h)
+hipError_t launch_generate(const WaveArgs &A, const RayStack &q, uint64_t slot0, uint64_t first, uint32_t count, hipStream_t st);
+hipError_t launch_trace(const DevScene &S, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count, hipStream_t st);
+hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
+                        const RayStack &dst, uint64_t dst_base, uint32_t *dst_count, hipStream_t st);
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st);
 
 } // namespace rt

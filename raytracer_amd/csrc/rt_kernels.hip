@@ -475,265 +475,279 @@ __device__ inline bool refract_dir(V3 d, V3 normal, double n, V3 &t)
     return false;
 }
 
-// ------------------------------------------------------------------ path tracing
-// Scene::rayColor (scene.cpp:194-304) unrolled into a per-lane loop over pending rays.
-//
-// A lane owns one pixel at a time and walks that pixel's sample slice in order, so the
-// per-pixel sum needs no atomics and is added in sample order like Scene::run
-// (scene.cpp:104-112).  Recursion becomes a pending-ray stack in global memory: shading a
-// vertex pushes one record per follow-up ray (bounce rays carry throughput x lobe colour,
-// shadow rays carry the radiance they deliver if unoccluded) and the loop pops the next
-// record, so all lanes of a wave meet at ONE traversal call per iteration whatever kind of
-// ray they carry.  Random numbers are keyed by the ray's position in the path tree, so the
-// order in which pending rays are served does not change any path.
-//
-// Pixels are handed to lanes through a global counter; the lanes of a wave that need work
-// take consecutive indices with one atomic (ballot + popcount), and consecutive indices are
-// the pixels of an 8 x 8 image tile.
-struct Job { V3 e, d; double t0, t1; V3 w; uint64_t key; int32_t jump; int32_t E; int32_t type; };
-
-__device__ __forceinline__ void job_push(const RenderArgs &A, uint64_t lane, uint64_t nlanes, int &sp, const Job &j)
+// ------------------------------------------------------------------ path tracing (wavefront)
+// Scene::rayColor (scene.cpp:194-304) as a pipeline over pools of pending rays.  Recursion
+// becomes data: shading a vertex appends one record per follow-up ray (a bounce ray carries
+// throughput x lobe colour, a shadow ray carries the radiance it delivers if unoccluded), and
+// every contribution is added to its pixel's sum with a hardware fp64 atomic.  Random numbers
+// are keyed by a ray's position in the path tree, so the order in which rays are served does
+// not change any path; only the order of the fp64 additions into a pixel varies.
+__device__ __forceinline__ uint64_t pack_meta(uint32_t pix, uint32_t k, int32_t jump, int32_t E, int32_t kind)
 {
-    if (sp >= A.stack_cap) { *A.overflow = 1; return; }
-    uint64_t *b = A.jobs + ((uint64_t)sp * JOB_FIELDS) * nlanes + lane;
-    b[JOB_EX * nlanes] = __double_as_longlong(j.e.x); b[JOB_EY * nlanes] = __double_as_longlong(j.e.y); b[JOB_EZ * nlanes] = __double_as_longlong(j.e.z);
-    b[JOB_DX * nlanes] = __double_as_longlong(j.d.x); b[JOB_DY * nlanes] = __double_as_longlong(j.d.y); b[JOB_DZ * nlanes] = __double_as_longlong(j.d.z);
-    b[JOB_T1 * nlanes] = __double_as_longlong(j.t1);
-    b[JOB_WX * nlanes] = __double_as_longlong(j.w.x); b[JOB_WY * nlanes] = __double_as_longlong(j.w.y); b[JOB_WZ * nlanes] = __double_as_longlong(j.w.z);
-    b[JOB_KEY * nlanes] = j.key;
-    b[JOB_META * nlanes] = (uint64_t)(uint32_t)j.jump | ((uint64_t)(j.E & 1) << 32) | ((uint64_t)(j.type & 1) << 33);
-    sp++;
+    return (uint64_t)pix | ((uint64_t)(k & 0xFFFFFFu) << 32) | ((uint64_t)(jump & 63) << 56) | ((uint64_t)(E & 1) << 62) | ((uint64_t)(kind & 1) << 63);
 }
-__device__ __forceinline__ void job_pop(const RenderArgs &A, uint64_t lane, uint64_t nlanes, int &sp, Job &j)
+__device__ __forceinline__ void ray_store(const RayStack &q, uint64_t slot, V3 e, V3 d, double t1, V3 w, uint64_t key, uint64_t meta)
 {
-    sp--;
-    const uint64_t *b = A.jobs + ((uint64_t)sp * JOB_FIELDS) * nlanes + lane;
-    j.e = mk(__longlong_as_double(b[JOB_EX * nlanes]), __longlong_as_double(b[JOB_EY * nlanes]), __longlong_as_double(b[JOB_EZ * nlanes]));
-    j.d = mk(__longlong_as_double(b[JOB_DX * nlanes]), __longlong_as_double(b[JOB_DY * nlanes]), __longlong_as_double(b[JOB_DZ * nlanes]));
-    j.t0 = RT_ZERO;
-    j.t1 = __longlong_as_double(b[JOB_T1 * nlanes]);
-    j.w = mk(__longlong_as_double(b[JOB_WX * nlanes]), __longlong_as_double(b[JOB_WY * nlanes]), __longlong_as_double(b[JOB_WZ * nlanes]));
-    j.key = b[JOB_KEY * nlanes];
-    uint64_t meta = b[JOB_META * nlanes];
-    j.jump = (int32_t)(uint32_t)meta;
-    j.E = (int32_t)((meta >> 32) & 1);
-    j.type = (int32_t)((meta >> 33) & 1);
+    uint64_t *b = q.f + slot;
+    const uint64_t c = q.cap;
+    b[RAY_EX * c] = __double_as_longlong(e.x); b[RAY_EY * c] = __double_as_longlong(e.y); b[RAY_EZ * c] = __double_as_longlong(e.z);
+    b[RAY_DX * c] = __double_as_longlong(d.x); b[RAY_DY * c] = __double_as_longlong(d.y); b[RAY_DZ * c] = __double_as_longlong(d.z);
+    b[RAY_T1 * c] = __double_as_longlong(t1);
+    b[RAY_WX * c] = __double_as_longlong(w.x); b[RAY_WY * c] = __double_as_longlong(w.y); b[RAY_WZ * c] = __double_as_longlong(w.z);
+    b[RAY_KEY * c] = key;
+    b[RAY_META * c] = meta;
+}
+__device__ __forceinline__ double ray_f(const RayStack &q, uint64_t slot, int field) { return __longlong_as_double(q.f[(uint64_t)field * q.cap + slot]); }
+
+// Wave-aggregated append: the lanes that want a slot take consecutive ones with one atomic
+// (ballot + popcount).  Returns this lane's slot (only meaningful where want is true).
+__device__ __forceinline__ uint64_t wave_append(uint32_t *counter, bool want)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader, 64);
+    return (uint64_t)base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_render(DevScene S, RenderArgs A)
+// Pixel enumeration: 8 x 8 tiles over the part of the image that whole tiles cover, then the
+// right and top remainders row by row (a bijection on [0, W*H) for any size).
+__device__ __forceinline__ void work_pixel(uint32_t idx, int W, int H, int &x, int &y)
+{
+    const uint32_t Wt = (uint32_t)W & ~7u, Ht = (uint32_t)H & ~7u;
+    const uint32_t tiled = Wt * Ht;
+    if (idx < tiled) {
+        const uint32_t tile = idx >> 6, l = idx & 63u, tx = Wt >> 3;
+        x = (int)((tile % tx) * 8 + (l & 7u));
+        y = (int)((tile / tx) * 8 + (l >> 3));
+        return;
+    }
+    idx -= tiled;
+    const uint32_t rw = (uint32_t)W - Wt;
+    if (idx < rw * (uint32_t)H) { x = (int)(Wt + idx % rw); y = (int)(idx / rw); return; }
+    idx -= rw * (uint32_t)H;
+    x = (int)(idx % Wt); y = (int)(Ht + idx / Wt);
+}
+
+// First rays of work items [first, first+count): item = sample-major (all pixels of sample k,
+// then k+1) so that neighbouring lanes start neighbouring pixels with the same sample index.
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(WaveArgs A, RayStack q, uint64_t slot0, uint64_t first, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t item = first + i;
+    V3 e, d;
+    double t1;
+    uint32_t pix, k;
+    if (A.batch) {
+        pix = (uint32_t)item; k = 0;
+        e = ld3(A.rays[item].e); d = ld3(A.rays[item].d);
+        t1 = A.t1;
+    } else {
+        const uint64_t npix = (uint64_t)A.width * (uint64_t)A.height;
+        k = (uint32_t)A.sample_begin + (uint32_t)(item / npix);
+        int x, y;
+        work_pixel((uint32_t)(item % npix), A.width, A.height, x, y);
+        pix = (uint32_t)y * (uint32_t)A.width + (uint32_t)x;
+        double jx, jy;                                          // Scene::run, scene.cpp:105-108
+        jitter_pair(A.seed, pix, 0, k, (uint32_t)A.n, (uint32_t)A.m, jx, jy);
+        camera_ray(A.cam, (float)((jx + x * 1.0) / A.width), (float)((jy + y * 1.0) / A.height), e, d);
+        t1 = A.t1;
+    }
+    ray_store(q, slot0 + i, e, d, t1, mk(1, 1, 1), path_root_key(A.seed, pix, k), pack_meta(pix, k, A.jumptime, 1, RAY_RADIANCE));
+}
+
+// Closest hit for the chunk [base, base+count) of a ray stack.
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, WaveArgs A, RayStack q, uint64_t base, uint32_t count)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    const uint64_t nlanes = (uint64_t)gridDim.x * RT_BLOCK;
-    const uint64_t lane = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t lane_in_wave = threadIdx.x & 63;
-
-    // work items: batch mode = rays; camera mode = pixels enumerated tile by tile (8 x 8)
-    const uint32_t tiles_x = A.batch ? 0u : (uint32_t)((A.width + 7) >> 3);
-    const uint32_t tiles_y = A.batch ? 0u : (uint32_t)((A.height + 7) >> 3);
-    const uint64_t total = A.batch ? A.nrays : (uint64_t)tiles_x * tiles_y * 64ull;
-    const uint32_t tab_n = A.batch ? 1u : (uint32_t)A.n, tab_m = A.batch ? 1u : (uint32_t)A.m;
-
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     Counters c = { 0, 0, 0, 0 };
-    V3 psum = mk(0, 0, 0);
-    uint64_t pix = 0;          // pixel index (row-major) or ray index: the sampler's pixel key
-    int px = 0, py = 0;
-    int k = 0, k_end = 0;      // current / one-past-last sample index of the owned pixel
-    bool own = false;          // lane owns a work item
-    bool exhausted = false;    // the global counter ran out
-    int sp = 0;
-    Job job;
-    bool have = false;
-
-    for (;;) {
-        // ---- phase A: give every lane without a ray its next ray
-        if (!have) {
-            if (sp > 0) {
-                job_pop(A, lane, nlanes, sp, job);
-                have = true;
-            } else {
-                if (own) {
-                    k++;
-                    if (k >= k_end) {                        // item finished: write its sum
-                        double *o = A.out + 3 * pix;
-                        if (A.batch) { o[0] = psum.x; o[1] = psum.y; o[2] = psum.z; }
-                        else { o[0] += psum.x; o[1] += psum.y; o[2] += psum.z; }
-                        own = false;
-                    }
-                }
-                if (!own && !exhausted) {
-                    // wave-aggregated fetch: lanes that need work take consecutive indices
-                    const unsigned long long need = __ballot(1);
-                    const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
-                    const uint32_t cntw = (uint32_t)__popcll(need);
-                    uint32_t base = 0;
-                    if (lane_in_wave == leader) base = atomicAdd(A.next_work, cntw);
-                    base = __shfl(base, (int)leader, 64);
-                    const uint64_t idx = (uint64_t)base + (uint64_t)__popcll(need & ((1ull << lane_in_wave) - 1ull));
-                    if (idx >= total) {
-                        exhausted = true;
-                    } else if (A.batch) {
-                        pix = idx; own = true; k = 0; k_end = 1; psum = mk(0, 0, 0);
-                    } else {
-                        const uint32_t tile = (uint32_t)(idx >> 6), l = (uint32_t)(idx & 63);
-                        px = (int)((tile % tiles_x) * 8 + (l & 7));
-                        py = (int)((tile / tiles_x) * 8 + (l >> 3));
-                        if (px < A.width && py < A.height && A.sample_begin < A.sample_end) {
-                            pix = (uint64_t)py * A.width + px;
-                            own = true; k = A.sample_begin; k_end = A.sample_end; psum = mk(0, 0, 0);
-                        }
-                    }
-                }
-                if (own) {                                   // first ray of sample k
-                    if (A.batch) {
-                        job.e = ld3(A.rays[pix].e); job.d = ld3(A.rays[pix].d);
-                        job.t0 = A.t0; job.t1 = A.t1; job.jump = A.jumptime;
-                    } else {
-                        double jx, jy;                         // Scene::run, scene.cpp:105-108
-                        jitter_pair(A.seed, pix, 0, (uint32_t)k, tab_n, tab_m, jx, jy);
-                        camera_ray(A.cam, (float)((jx + px * 1.0) / A.width), (float)((jy + py * 1.0) / A.height), job.e, job.d);
-                        job.t0 = 0; job.t1 = RT_INFINITE; job.jump = 0;
-                    }
-                    job.w = mk(1, 1, 1); job.E = 1; job.type = JOB_RADIANCE;
-                    job.key = path_root_key(A.seed, pix, (uint32_t)k);
-                    have = true;
-                }
-            }
+    if (i < count) {
+        const uint64_t slot = base + i;
+        const uint64_t meta = q.f[(uint64_t)RAY_META * q.cap + slot];
+        const int jump = (int)((meta >> 56) & 63);
+        const bool shadow = (meta >> 63) != 0;
+        uint64_t id = ~0ull;
+        double t = RT_INFINITE;
+        // depth cut-off (scene.cpp:196-198) happens before any intersection work
+        if (shadow || jump + 1 <= A.max_jump) {
+            V3 e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
+            V3 d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
+            const bool first = !shadow && jump == A.jumptime && ((meta >> 62) & 1);
+            const double t0 = first ? A.t0 : RT_ZERO;
+            const double t1 = ray_f(q, slot, RAY_T1);
+            Hit h;
+            if (group_hit<RT_BLOCK>(S, e, d, t0, t1, h, stk, c)) { id = ((uint64_t)(uint32_t)h.obj << 32) | h.prim; t = h.t; }
         }
-        if (__ballot(have || own || sp > 0 || !exhausted) == 0ull) break;
-
-        // ---- depth cut-off (scene.cpp:196-198) happens before any intersection work
-        int jt = 0;
-        if (have && job.type == JOB_RADIANCE) {
-            jt = job.jump + 1;
-            if (jt > A.max_jump) {
-                psum = psum + had(job.w, ld3(S.background));
-                have = false;
-            }
-        }
-
-        // ---- phase B: one closest-hit query per lane that carries a ray
-        Hit h;
-        bool hit = false;
-        if (have) hit = group_hit<RT_BLOCK>(S, job.e, job.d, job.t0, job.t1, h, stk, c);
-
-        // ---- phase C: consume the result
-        if (have) {
-            have = false;
-            if (job.type == JOB_SHADOW) {
-                if (!hit) psum = psum + job.w;                // scene.cpp:236-238
-            } else if (!hit) {
-                psum = psum + had(job.w, ld3(S.background));   // scene.cpp:378-380
-            } else {
-                const rt_material &mat = S.materials[S.objects[h.obj].material];
-                const V3 p = job.e + job.d * h.t;
-                const V3 normal = hit_normal(S, h, p);
-                const V3 emission = ld3(mat.emission), mcolor = ld3(mat.color);
-                const double Ed = (double)job.E;
-                const V3 W = job.w;
-                V3 cc = mcolor;
-                bool alive = true;
-                if (jt > A.rus_jump) {                         // Russian roulette, scene.cpp:208-212
-                    double pr = (cc.x > cc.y && cc.x > cc.z) ? cc.x : (cc.y > cc.z ? cc.y : cc.z);
-                    if (draw(job.key, SLOT_RR) < pr) cc = cc * (1 / pr);
-                    else { psum = psum + had(W, emission * Ed); alive = false; }
-                }
-                if (alive && (mat.type & RT_MAT_NORMAL)) {      // scene.cpp:213-248
-                    double r1 = RT_PI * 2 * draw(job.key, SLOT_DIFF1);
-                    double r2 = draw(job.key, SLOT_DIFF2), r2s = sqrt(r2);
-                    V3 w = normal;
-                    if (A.face_forward && dot(w, job.d) > 0) w = -w;
-                    V3 u = norm(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
-                    V3 v = cross(w, u);
-                    V3 dn = norm(((u * cos(r1)) * r2s + (v * sin(r1)) * r2s) + w * sqrt(1 - r2));
-                    psum = psum + had(W, emission * Ed);
-                    Job nj;
-                    nj.e = p; nj.d = dn; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.w = had(W, mcolor);
-                    nj.key = hash2(job.key, BR_DIFFUSE); nj.jump = jt + 1; nj.E = 0; nj.type = JOB_RADIANCE;
-                    job_push(A, lane, nlanes, sp, nj);
-                    const V3 wn = norm(w);
-                    for (int li = 0; li < S.nlights; li++) {     // next-event estimation, scene.cpp:223-246
-                        const rt_light &L = S.lights[li];
-                        double lu, lv;
-                        jitter_pair(A.seed, pix, 1u + (uint32_t)li, (uint32_t)k, tab_n, tab_m, lu, lv);
-                        V3 nl; double pr;
-                        V3 ppos = job.d * h.t + job.e;           // light.cpp:143
-                        V3 lightpos = light_sample(L, ppos, lu, lv, nl, pr);
-                        if (pr > RT_INFINITE) continue;
-                        double dist = len(lightpos - p);
-                        V3 ldir = norm(lightpos - p);
-                        double dt = dot(nl, -ldir);
-                        double dt2 = dot(wn, ldir);
-                        if (dt < 0 || dt2 < 0) continue;
-                        V3 ld = ((ld3(L.diffuse) * dt) * dt2) * (1 / pr / dist / dist);
-                        Job sj;
-                        sj.e = p; sj.d = ldir; sj.t0 = RT_ZERO; sj.t1 = dist - RT_ZERO; sj.w = had(W, had(cc, ld));
-                        sj.key = 0; sj.jump = 0; sj.E = 0; sj.type = JOB_SHADOW;
-                        job_push(A, lane, nlanes, sp, sj);
-                    }
-                }
-                if (alive && (mat.type & RT_MAT_SPECULAR)) {    // scene.cpp:249-266
-                    V3 md = job.d - (normal * dot(normal, job.d)) * 2;
-                    if (mat.blur >= RT_ZERO) {
-                        V3 vec = mk(0, 0, 1);
-                        if (iszero(cross(vec, md))) vec = mk(0, 1, 0);
-                        V3 u = norm(cross(vec, md));
-                        V3 v = norm(cross(md, u));
-                        double x, y;
-                        uint32_t a = 0;
-                        do {                                     // randFromDisk, algorithms.h:30-35
-                            x = (draw(job.key, SLOT_DISK + 2 * a) - 0.5) * 2;
-                            y = (draw(job.key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
-                            a++;
-                        } while (x * x + y * y >= 1.0);
-                        x *= mat.blur; y *= mat.blur;
-                        md = (md + u * x) + v * y;
-                    }
-                    psum = psum + had(W, emission * Ed);
-                    Job nj;
-                    nj.e = p; nj.d = md; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.w = had(W, mcolor);
-                    nj.key = hash2(job.key, BR_SPECULAR); nj.jump = jt; nj.E = 1; nj.type = JOB_RADIANCE;
-                    job_push(A, lane, nlanes, sp, nj);
-                }
-                if (alive && (mat.type & RT_MAT_TRANSPARENT)) { // scene.cpp:267-303
-                    V3 kk = mk(1, 1, 1);
-                    double cosv = 0;
-                    V3 r = reflact(job.d, normal);
-                    V3 rd = mk(0, 0, 0);
-                    bool tir = false;
-                    if (dot(normal, job.d) > 0) {
-                        kk.x = exp(-mat.atten[0] * h.t);
-                        kk.y = exp(-mat.atten[1] * h.t);
-                        kk.z = exp(-mat.atten[2] * h.t);
-                        if (refract_dir(job.d, -normal, 1 / mat.nr, rd)) {
-                            tir = true;
-                            psum = psum + had(W, emission * Ed);
-                            Job nj;
-                            nj.e = p; nj.d = r; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.w = had(W, kk);
-                            nj.key = hash2(job.key, BR_REFLECT); nj.jump = jt; nj.E = 1; nj.type = JOB_RADIANCE;
-                            job_push(A, lane, nlanes, sp, nj);
-                        } else {
-                            cosv = dot(rd, normal);
-                        }
-                    } else {
-                        cosv = dot(-job.d, normal);
-                        refract_dir(job.d, normal, mat.nr, rd);
-                    }
-                    if (!tir) {
-                        double n = mat.nr;
-                        double R0 = (n - 1) * (n - 1) / (n + 1) / (n + 1);
-                        double R = R0 + (1 - R0) * pow(1 - cosv, 5.0);
-                        Job nj;
-                        nj.e = p; nj.t0 = RT_ZERO; nj.t1 = RT_INFINITE; nj.jump = jt; nj.E = 1; nj.type = JOB_RADIANCE;
-                        nj.d = rd; nj.w = had(W, kk * (1 - R)); nj.key = hash2(job.key, BR_REFRACT);
-                        job_push(A, lane, nlanes, sp, nj);
-                        nj.d = r; nj.w = had(W, kk * R); nj.key = hash2(job.key, BR_REFLECT);
-                        job_push(A, lane, nlanes, sp, nj);
-                    }
-                }
-            }
-        }
+        q.hit_t[slot] = t;
+        q.hit_id[slot] = id;
     }
     flush_counters(A.counters, c);
+}
+
+__device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
+{
+    if (v.x != 0.0) unsafeAtomicAdd(out + 3ull * pix, v.x);
+    if (v.y != 0.0) unsafeAtomicAdd(out + 3ull * pix + 1, v.y);
+    if (v.z != 0.0) unsafeAtomicAdd(out + 3ull * pix + 2, v.z);
+}
+
+// Consume the hits of chunk [base, base+count) of `src`; follow-up rays go to `dst` at
+// dst_base + (*dst_count)++.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayStack src, uint64_t base, uint32_t count,
+                                                     RayStack dst, uint64_t dst_base, uint32_t *dst_count)
+{
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool live = i < count;
+    const uint64_t slot = base + (live ? i : 0);
+    const uint64_t meta = src.f[(uint64_t)RAY_META * src.cap + slot];
+    const uint32_t pix = (uint32_t)meta, k = (uint32_t)(meta >> 32) & 0xFFFFFFu;
+    const int jump = (int)((meta >> 56) & 63), E = (int)((meta >> 62) & 1);
+    const bool shadow = (meta >> 63) != 0;
+    const uint64_t id = src.hit_id[slot];
+    const bool hit = id != ~0ull;
+    const V3 W = mk(ray_f(src, slot, RAY_WX), ray_f(src, slot, RAY_WY), ray_f(src, slot, RAY_WZ));
+    const uint32_t tab_n = A.batch ? 1u : (uint32_t)A.n, tab_m = A.batch ? 1u : (uint32_t)A.m;
+
+    V3 sum = mk(0, 0, 0);                 // everything this ray adds to its pixel
+    bool shade = false;
+    if (live) {
+        if (shadow) { if (!hit) sum = W; }                                   // scene.cpp:236-238
+        else if (!hit) sum = had(W, ld3(S.background));                      // scene.cpp:196-198, 378-380
+        else shade = true;
+    }
+    // values every push site needs
+    const V3 re = mk(ray_f(src, slot, RAY_EX), ray_f(src, slot, RAY_EY), ray_f(src, slot, RAY_EZ));
+    const V3 rd = mk(ray_f(src, slot, RAY_DX), ray_f(src, slot, RAY_DY), ray_f(src, slot, RAY_DZ));
+    const uint64_t key = src.f[(uint64_t)RAY_KEY * src.cap + slot];
+    const double ht = src.hit_t[slot];
+    const int jt = jump + 1;
+    Hit h; h.t = ht; h.obj = (int32_t)(id >> 32); h.prim = (uint32_t)id;
+    if (!shade) { h.obj = 0; h.prim = 0; }
+    const rt_material &mat = S.materials[shade ? S.objects[h.obj].material : 0];
+    const int mtype = shade ? mat.type : 0;
+    const V3 p = re + rd * ht;
+    V3 normal = mk(0, 1, 0);
+    if (shade) normal = hit_normal(S, h, p);
+    const V3 emission = ld3(mat.emission), mcolor = ld3(mat.color);
+    const double Ed = (double)E;
+    V3 cc = mcolor;
+    bool alive = shade;
+    if (shade && jt > A.rus_jump) {                                          // Russian roulette, scene.cpp:208-212
+        double pr = (cc.x > cc.y && cc.x > cc.z) ? cc.x : (cc.y > cc.z ? cc.y : cc.z);
+        if (draw(key, SLOT_RR) < pr) cc = cc * (1 / pr);
+        else { sum = sum + had(W, emission * Ed); alive = false; }
+    }
+
+    // ---- diffuse lobe, scene.cpp:213-248
+    const bool lobeN = alive && (mtype & RT_MAT_NORMAL);
+    V3 w = normal, dn = mk(0, 0, 0), wn = normal;
+    if (lobeN) {
+        double r1 = RT_PI * 2 * draw(key, SLOT_DIFF1);
+        double r2 = draw(key, SLOT_DIFF2), r2s = sqrt(r2);
+        if (A.face_forward && dot(w, rd) > 0) w = -w;
+        V3 u = norm(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
+        V3 v = cross(w, u);
+        dn = norm(((u * cos(r1)) * r2s + (v * sin(r1)) * r2s) + w * sqrt(1 - r2));
+        wn = norm(w);
+        sum = sum + had(W, emission * Ed);
+    }
+    {
+        const uint64_t s = wave_append(dst_count, lobeN);
+        if (lobeN) ray_store(dst, dst_base + s, p, dn, RT_INFINITE, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0, RAY_RADIANCE));
+    }
+    for (int li = 0; li < S.nlights; li++) {                                 // next-event estimation, scene.cpp:223-246
+        bool want = false;
+        V3 ldir = mk(0, 0, 0), contrib = mk(0, 0, 0);
+        double dist = 0;
+        if (lobeN) {
+            const rt_light &L = S.lights[li];
+            double lu, lv;
+            jitter_pair(A.seed, pix, 1u + (uint32_t)li, k, tab_n, tab_m, lu, lv);
+            V3 nl; double pr;
+            V3 ppos = rd * ht + re;                                          // light.cpp:143
+            V3 lightpos = light_sample(L, ppos, lu, lv, nl, pr);
+            if (!(pr > RT_INFINITE)) {
+                dist = len(lightpos - p);
+                ldir = norm(lightpos - p);
+                double dt = dot(nl, -ldir);
+                double dt2 = dot(wn, ldir);
+                if (!(dt < 0 || dt2 < 0)) {
+                    V3 ld = ((ld3(L.diffuse) * dt) * dt2) * (1 / pr / dist / dist);
+                    contrib = had(W, had(cc, ld));
+                    want = true;
+                }
+            }
+        }
+        const uint64_t s = wave_append(dst_count, want);
+        if (want) ray_store(dst, dst_base + s, p, ldir, dist - RT_ZERO, contrib, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
+    }
+
+    // ---- mirror lobe, scene.cpp:249-266
+    const bool lobeS = alive && (mtype & RT_MAT_SPECULAR);
+    V3 md = mk(0, 0, 0);
+    if (lobeS) {
+        md = rd - (normal * dot(normal, rd)) * 2;
+        if (mat.blur >= RT_ZERO) {
+            V3 vec = mk(0, 0, 1);
+            if (iszero(cross(vec, md))) vec = mk(0, 1, 0);
+            V3 u = norm(cross(vec, md));
+            V3 v = norm(cross(md, u));
+            double x, y;
+            uint32_t a = 0;
+            do {                                                             // randFromDisk, algorithms.h:30-35
+                x = (draw(key, SLOT_DISK + 2 * a) - 0.5) * 2;
+                y = (draw(key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
+                a++;
+            } while (x * x + y * y >= 1.0);
+            x *= mat.blur; y *= mat.blur;
+            md = (md + u * x) + v * y;
+        }
+        sum = sum + had(W, emission * Ed);
+    }
+    {
+        const uint64_t s = wave_append(dst_count, lobeS);
+        if (lobeS) ray_store(dst, dst_base + s, p, md, RT_INFINITE, had(W, mcolor), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+    }
+
+    // ---- dielectric lobe, scene.cpp:267-303
+    const bool lobeT = alive && (mtype & RT_MAT_TRANSPARENT);
+    V3 kk = mk(1, 1, 1), r = mk(0, 0, 0), rfr = mk(0, 0, 0);
+    double R = 0;
+    bool tir = false;
+    if (lobeT) {
+        double cosv = 0;
+        r = reflact(rd, normal);
+        if (dot(normal, rd) > 0) {
+            kk.x = exp(-mat.atten[0] * ht);
+            kk.y = exp(-mat.atten[1] * ht);
+            kk.z = exp(-mat.atten[2] * ht);
+            if (refract_dir(rd, -normal, 1 / mat.nr, rfr)) { tir = true; sum = sum + had(W, emission * Ed); }
+            else cosv = dot(rfr, normal);
+        } else {
+            cosv = dot(-rd, normal);
+            refract_dir(rd, normal, mat.nr, rfr);
+        }
+        if (!tir) {
+            double n = mat.nr;
+            double R0 = (n - 1) * (n - 1) / (n + 1) / (n + 1);
+            R = R0 + (1 - R0) * pow(1 - cosv, 5.0);
+        }
+    }
+    {
+        // reflected ray: weight k (total internal reflection) or k*R
+        const uint64_t s = wave_append(dst_count, lobeT);
+        if (lobeT) ray_store(dst, dst_base + s, p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        const bool wantT = lobeT && !tir;
+        const uint64_t s2 = wave_append(dst_count, wantT);
+        if (wantT) ray_store(dst, dst_base + s2, p, rfr, RT_INFINITE, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+    }
+
+    if (live) add_radiance(A.out, pix, sum);
 }
 
 // colorArray_ -> bytes: average, regularize (types.h:167-177), int(c*255) as B,G,R (scene.cpp:183-185)
@@ -769,16 +783,23 @@ hipError_t launch_trace_primary(const DevScene &S, const rt_camera &cam, int w, 
     hipLaunchKernelGGL(k_trace_primary, dim3(blocks), dim3(RT_BLOCK), 0, st, S, cam, w, h, prim_id, t, counters);
     return hipGetLastError();
 }
-int render_blocks_per_cu()
+hipError_t launch_generate(const WaveArgs &A, const RayStack &q, uint64_t slot0, uint64_t first, uint32_t count, hipStream_t st)
 {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render, RT_BLOCK, 0) != hipSuccess || nb < 1) nb = 1;
-    if (nb > 4) nb = 4;
-    return nb;
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_generate, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, A, q, slot0, first, count);
+    return hipGetLastError();
 }
-hipError_t launch_render(const DevScene &S, const RenderArgs &A, unsigned blocks, hipStream_t st)
+hipError_t launch_trace(const DevScene &S, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RT_BLOCK), 0, st, S, A);
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_trace, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, q, base, count);
+    return hipGetLastError();
+}
+hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
+                        const RayStack &dst, uint64_t dst_base, uint32_t *dst_count, hipStream_t st)
+{
+    if (!count) return hipSuccess;
+    hipLaunchKernelGGL(k_shade, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, src, base, count, dst, dst_base, dst_count);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st)
