@@ -159,6 +159,9 @@ int rt_ray_color_host(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0
  * partial sums from several devices can be added first). */
 int rt_render(rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
               double *radiance_sum, uint64_t *counters, void *stream);
+/* rt_render and rt_ray_color run a multi-launch pipeline that reads one counter back per
+ * round, so unlike the other device-pointer entry points they return when the work on
+ * `stream` is complete. */
 int rt_render_host(rt_scene *scene, const rt_camera *cam, const rt_render_params *params,
                    double *radiance_sum, uint64_t *counters);
 
@@ -167,6 +170,14 @@ int rt_render_host(rt_scene *scene, const rt_camera *cam, const rt_render_params
  * derived from the materials, so this is a should-not-happen check).  The _host variants call
  * it themselves.  No counterpart in the reference. */
 int rt_scene_check(rt_scene *scene, void *stream);
+
+/* Stage timing for measurement (no counterpart in the reference): when enabled, later
+ * rt_render / rt_ray_color calls bracket every closest-hit and every shading launch with HIP
+ * events on the caller's stream.  rt_scene_get_profile: out = {closest-hit launches, their
+ * total ms, shading launches, their total ms, first-ray launches, rounds}; reset != 0 zeroes
+ * the totals after reading. */
+int rt_scene_set_profiling(rt_scene *scene, int enable);
+int rt_scene_get_profile(rt_scene *scene, double out[6], int reset);
 
 /* colorArray_ -> bytes: average, Vec4::regularize (types.h:167-177), int(c*255) stored B,G,R
  * (scene.cpp:183-185).  bgr = height x width x 3 bytes, bottom row first. */

@@ -66,15 +66,17 @@ public:
         ++tests;
         Vec3 p = ray.d ^ e2_;
         double det = e1_ * p;
-        if (!(fabs(det) >= 1e-200)) return false;
-        double inv = 1.0 / det;
+        double a = fabs(det);
+        if (!(a >= 1e-200)) return false;
         Vec3 s = ray.e - v0_;
-        double u = (s * p) * inv;
-        if (!(u >= 0.0 && u <= 1.0)) return false;
+        double up = s * p;
+        double us = det < 0 ? -up : up;
+        if (!(us >= 0.0 && us <= a)) return false;
         Vec3 q = s ^ e1_;
-        double v = (ray.d * q) * inv;
-        if (!(v >= 0.0 && u + v <= 1.0)) return false;
-        double t = (e2_ * q) * inv;
+        double vp = ray.d * q;
+        double vs = det < 0 ? -vp : vp;
+        if (!(vs >= 0.0 && us + vs <= a)) return false;
+        double t = (e2_ * q) / det;
         if (!(t >= t0 && t <= t1)) return false;
         rec->t = t;
         rec->localp = Vec3((double)id_, 0, 0);

@@ -255,22 +255,26 @@ int orc_plane_hit(int type, double coord, const orc_ray *r, double t0, double t1
 {
     return plane_hit(type, coord, rayp(r), t0, t1, t);
 }
-/* New primitive (no reference counterpart): two-sided Moeller-Trumbore, one division.
- * Takes the place of BoxNode::calHit (Surface.cpp:43-59) as the octree payload test. */
+/* New primitive (no reference counterpart): two-sided Moeller-Trumbore.  The barycentric
+ * tests are made on the un-normalised numerators against |det| (exact sign flips instead of
+ * a multiplication by 1/det), so the only division is the one that produces t for a ray that
+ * passed them.  Takes the place of BoxNode::calHit (Surface.cpp:43-59) as the octree payload. */
 #define TRI_DET_EPS 1e-200
 static int triangle_hit(v3 v0, v3 e1, v3 e2, ray_t r, double t0, double t1, double *tout)
 {
     v3 p = vcross(r.d, e2);
     double det = vdot(e1, p);
-    if (!(fabs(det) >= TRI_DET_EPS)) return 0;
-    double inv = 1.0 / det;
+    double a = fabs(det);
+    if (!(a >= TRI_DET_EPS)) return 0;
     v3 s = vsub(r.e, v0);
-    double u = vdot(s, p) * inv;
-    if (!(u >= 0.0 && u <= 1.0)) return 0;
+    double up = vdot(s, p);
+    double us = det < 0 ? -up : up;
+    if (!(us >= 0.0 && us <= a)) return 0;
     v3 q = vcross(s, e1);
-    double v = vdot(r.d, q) * inv;
-    if (!(v >= 0.0 && u + v <= 1.0)) return 0;
-    double t = vdot(e2, q) * inv;
+    double vp = vdot(r.d, q);
+    double vs = det < 0 ? -vp : vp;
+    if (!(vs >= 0.0 && us + vs <= a)) return 0;
+    double t = vdot(e2, q) / det;
     if (!(t >= t0 && t <= t1)) return 0;
     *tout = t;
     return 1;

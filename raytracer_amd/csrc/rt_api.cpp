@@ -55,6 +55,10 @@ struct rt_scene {
     uint32_t *d_ctrl = nullptr;   // [0] rays appended by the running shade kernel
     uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0]
     int failed = 0;               // a render ran out of ray-stack space
+    // optional stage timing
+    int profiling = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    double prof[6] = {0, 0, 0, 0, 0, 0}; // trace launches, trace ms, shade launches, shade ms, generate launches, rounds
 };
 
 extern "C" {
@@ -113,6 +117,7 @@ int rt_scene_destroy(rt_scene *s)
     for (int k = 0; k < 2; k++) if (s->stack_mem[k]) (void)hipFree(s->stack_mem[k]);
     if (s->d_ctrl) (void)hipFree(s->d_ctrl);
     if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
+    for (int k = 0; k < 3; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     delete s;
     return 0;
 }
@@ -316,6 +321,7 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
             uint64_t m = target - count[src];
             if (m > total_items - issued) m = total_items - issued;
             HIP_TRY(launch_generate(A, s->stack[src], count[src], issued, (uint32_t)m, st));
+            s->prof[4] += 1;
             count[src] += m;
             issued += m;
         }
@@ -326,11 +332,21 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
         if (c > room) c = room;
         if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
         const uint64_t base = count[src] - c;
-        HIP_TRY(launch_trace(s->dev, A, s->stack[src], base, (uint32_t)c, st));
         HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 4, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+        HIP_TRY(launch_trace(s->dev, A, s->stack[src], base, (uint32_t)c, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
         HIP_TRY(launch_shade(s->dev, A, s->stack[src], base, (uint32_t)c, s->stack[dst], count[dst], s->d_ctrl, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
         HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->d_ctrl, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (s->profiling) {
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+            s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
+        }
+        s->prof[5] += 1;
         count[src] -= c;
         count[dst] += s->h_ctrl[0];
         if (s->h_ctrl[0]) src = dst;
@@ -390,6 +406,23 @@ int rt_scene_check(rt_scene *s, void *stream)
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (s->failed) return fail("an earlier path-tracing call ran out of ray-stack space");
+    return 0;
+}
+
+int rt_scene_set_profiling(rt_scene *s, int enable)
+{
+    if (!s) return fail("rt_scene_set_profiling: null scene");
+    HIP_TRY(hipSetDevice(s->device));
+    if (enable) for (int k = 0; k < 3; k++) if (!s->ev[k]) HIP_TRY(hipEventCreate(&s->ev[k]));
+    s->profiling = enable ? 1 : 0;
+    return 0;
+}
+
+int rt_scene_get_profile(rt_scene *s, double out[6], int reset)
+{
+    if (!s || !out) return fail("rt_scene_get_profile: null argument");
+    for (int k = 0; k < 6; k++) out[k] = s->prof[k];
+    if (reset) for (int k = 0; k < 6; k++) s->prof[k] = 0;
     return 0;
 }
 

@@ -127,21 +127,25 @@ __device__ __forceinline__ bool hit_box(const double *lo, const double *hi, V3 e
 struct Counters { uint32_t rays, inner, leaf, prim; };
 
 // Two-sided Moeller-Trumbore on the stored (v0, e1, e2) record; the octree payload test that
-// stands where BoxNode::calHit does in the reference (Surface.cpp:43-59).
+// stands where BoxNode::calHit does in the reference (Surface.cpp:43-59).  The barycentric
+// tests compare the un-normalised numerators with |det| (sign flips are exact), so a division
+// is only spent on rays that pass them.
 __device__ __forceinline__ bool tri_hit(const double *tr, V3 e, V3 d, double t0, double t1, double &tout)
 {
     V3 v0 = ld3(tr), e1 = ld3(tr + 3), e2 = ld3(tr + 6);
     V3 p = cross(d, e2);
     double det = dot(e1, p);
-    if (!(fabs(det) >= TRI_DET_EPS)) return false;
-    double inv = 1.0 / det;
+    double a = fabs(det);
+    if (!(a >= TRI_DET_EPS)) return false;
     V3 s = e - v0;
-    double u = dot(s, p) * inv;
-    if (!(u >= 0.0 && u <= 1.0)) return false;
+    double up = dot(s, p);
+    double us = det < 0 ? -up : up;
+    if (!(us >= 0.0 && us <= a)) return false;
     V3 q = cross(s, e1);
-    double v = dot(d, q) * inv;
-    if (!(v >= 0.0 && u + v <= 1.0)) return false;
-    double t = dot(e2, q) * inv;
+    double vp = dot(d, q);
+    double vs = det < 0 ? -vp : vp;
+    if (!(vs >= 0.0 && us + vs <= a)) return false;
+    double t = dot(e2, q) / det;
     if (!(t >= t0 && t <= t1)) return false;
     tout = t;
     return true;

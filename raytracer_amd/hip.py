@@ -20,7 +20,7 @@ EXPORTS = (
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
-    "rt_render_host", "rt_scene_check", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
+    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
 )
 
 _lib = None
@@ -56,6 +56,8 @@ def lib():
     L.rt_render.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _vp, _vp, _vp]
     L.rt_render_host.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _vp, _vp]
     L.rt_scene_check.argtypes = [_vp, _vp]
+    L.rt_scene_set_profiling.argtypes = [_vp, _int]
+    L.rt_scene_get_profile.argtypes = [_vp, _dp, _int]
     L.rt_resolve_bgr8.argtypes = [_vp, _int, _int, _int, _vp, _vp]
     L.rt_resolve_bgr8_host.argtypes = [_vp, _int, _int, _int, _vp]
     L.rt_save_bmp.argtypes = [_vp, _int, _int, C.c_char_p]
@@ -179,6 +181,14 @@ class HipScene:
     def trace_primary_dev(self, cam, w, h, prim_ptr, t_ptr=0, counters_ptr=0, stream=0):
         _chk(lib().rt_trace_primary(self._h, C.byref(cam), w, h, prim_ptr, t_ptr or None, counters_ptr or None, stream or None),
              "rt_trace_primary")
+
+    def set_profiling(self, enable=True):
+        _chk(lib().rt_scene_set_profiling(self._h, 1 if enable else 0), "rt_scene_set_profiling")
+
+    def get_profile(self, reset=True):
+        out = (C.c_double * 6)()
+        _chk(lib().rt_scene_get_profile(self._h, out, 1 if reset else 0), "rt_scene_get_profile")
+        return dict(zip(("trace_launches", "trace_ms", "shade_launches", "shade_ms", "generate_launches", "rounds"), out[:]))
 
     def check(self, stream=0):
         _chk(lib().rt_scene_check(self._h, stream or None), "rt_scene_check")

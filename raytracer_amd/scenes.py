@@ -164,9 +164,10 @@ def cornell_box_meshes(size=100.0, tess=1):
     return np.concatenate([floor, ceil_, back]), left, right
 
 
-def bunny_cornell_scene(nu=186, nv=187, light="sphere", glass=True, wall_tess=1):
+def bunny_cornell_scene(nu=186, nv=187, light="sphere", extras=False, wall_tess=1):
     """Bunny-class closed mesh (2*nu*nv triangles; default 69 564) inside a Cornell box made of
-    triangle meshes, one sphere (or rectangle) light, a mirror and a glass ball."""
+    triangle meshes with one sphere (or rectangle) light; extras=True adds a mirror ball and a
+    glass ball (used by the parity tests to cover the specular and dielectric lobes)."""
     white, red, green = cornell_box_meshes(100.0, wall_tess)
     body = blob((50, 32, 45), 24.0, nu, nv, seed=1)
     mats = [material(MAT_NORMAL, color=(.75, .75, .75)),        # 0 white
@@ -176,9 +177,9 @@ def bunny_cornell_scene(nu=186, nv=187, light="sphere", glass=True, wall_tess=1)
             material(MAT_SPECULAR, color=(.95, .95, .95)),      # 4 mirror
             material(MAT_TRANSPARENT, color=(.96, .96, .96), atten=(.004, .002, .006), nr=1.5),  # 5 glass
             material(MAT_NORMAL, emission=(36, 36, 36), color=(0, 0, 0))]   # 6 light geometry (light.cpp:113-115)
-    objs = [mesh_object(0, 0), mesh_object(1, 1), mesh_object(2, 2), mesh_object(3, 3),
-            sphere((22, 12, 70), 12.0, 4)]
-    if glass:
+    objs = [mesh_object(0, 0), mesh_object(1, 1), mesh_object(2, 2), mesh_object(3, 3)]
+    if extras:
+        objs.append(sphere((22, 12, 70), 12.0, 4))
         objs.append(sphere((78, 11, 78), 11.0, 5))
     lights = []
     if light == "sphere":

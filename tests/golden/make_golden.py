@@ -1,0 +1,137 @@
+"""Generates the golden vectors in this directory from the UNMODIFIED reference.
+
+Run in the build container (needs /root/reference and `make -C oracle`):
+    python tests/golden/make_golden.py
+Every .npz holds seeded inputs and the outputs the reference's own objects produced for them
+through oracle/_ref/libref_harness.so (ref_harness.cpp): data only, no reference source.
+The GPU box has no reference checkout; there the oracle and the HIP kernels are checked
+against these files.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import orc  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+from raytracer_amd.desc import RAY_DT  # noqa: E402
+
+
+def rand_rays(rng, n, lo=-1.0, hi=2.0, axis_frac=0.05):
+    r = np.zeros(n, RAY_DT)
+    r["e"] = rng.uniform(lo, hi, (n, 3))
+    d = rng.uniform(0, 1, (n, 3)) - r["e"]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # some rays with exactly-zero direction components (division by zero in the slab test)
+    k = int(n * axis_frac)
+    idx = rng.choice(n, k, replace=False)
+    for j, i in enumerate(idx):
+        d[i, j % 3] = 0.0
+        if j % 5 == 0:
+            d[i, (j + 1) % 3] = 0.0
+    r["d"] = d
+    return r
+
+
+def main():
+    assert orc.ref_available(), "build oracle/_ref first (make -C oracle)"
+    rng = np.random.default_rng(20260101)
+
+    # 1. hitBox (algorithms.h:223-236)
+    n = 4000
+    lo = rng.uniform(-1, 0.5, (n, 3)); hi = lo + rng.uniform(0.01, 1.5, (n, 3))
+    rays = rand_rays(rng, n, -2, 2, 0.15)
+    t0 = np.where(rng.random(n) < 0.5, 0.0, 1e-9); t1 = np.where(rng.random(n) < 0.7, 1e10, rng.uniform(0.1, 3, n))
+    out = np.zeros((n, 3))
+    for i in range(n):
+        out[i] = orc.ref_hit_box(lo[i], hi[i], rays["e"][i], rays["d"][i], t0[i], t1[i])
+    np.savez_compressed(os.path.join(HERE, "hit_box.npz"), lo=lo, hi=hi, e=rays["e"], d=rays["d"], t0=t0, t1=t1, out=out)
+
+    # 2. Sphere::hit + normal, planes (Surface.cpp:73-111,124-133,194-204,217-226)
+    n = 3000
+    c = rng.uniform(-1, 1, (n, 3)); rad = rng.uniform(0.05, 1.2, n)
+    rays = rand_rays(rng, n, -3, 3, 0.05)
+    # aim most rays at the sphere, un-normalised directions included
+    aim = c + rng.normal(0, 0.6, (n, 3)) * rad[:, None]
+    d = aim - rays["e"]; d *= rng.uniform(0.3, 3.0, (n, 1))
+    rays["d"] = d
+    t1 = np.where(rng.random(n) < 0.6, 1e10, rng.uniform(0.2, 4, n))
+    sph = np.zeros((n, 5))
+    for i in range(n):
+        h, t, nn = orc.ref_sphere_hit(c[i], rad[i], rays["e"][i], rays["d"][i], 1e-9, t1[i])
+        sph[i] = (h, t if h else 0, *(nn if h else (0, 0, 0)))
+    kinds = rng.integers(2, 5, n); coord = rng.uniform(-1, 1, n)
+    pl = np.zeros((n, 2))
+    for i in range(n):
+        h, t, nn = orc.ref_plane_hit(int(kinds[i]), coord[i], rays["e"][i], rays["d"][i], 1e-9, t1[i])
+        pl[i] = (h, t if h else 0)
+    np.savez_compressed(os.path.join(HERE, "sphere_plane.npz"), c=c, rad=rad, e=rays["e"], d=rays["d"], t1=t1, sph=sph,
+                        kinds=kinds, coord=coord, pl=pl)
+
+    # 3. getChildBound (octree.h:82-120)
+    n = 500
+    lo = rng.uniform(-5, 5, (n, 3)); hi = lo + rng.uniform(1e-3, 7, (n, 3))
+    cb = np.zeros((n, 8, 6))
+    for i in range(n):
+        for k in range(8):
+            a, b = orc.ref_child_bound(lo[i], hi[i], k)
+            cb[i, k, :3], cb[i, k, 3:] = a, b
+    np.savez_compressed(os.path.join(HERE, "child_bound.npz"), lo=lo, hi=hi, out=cb)
+
+    # 4. Camera::init / getRay (camera.cpp:24-48)
+    n = 200
+    frm = rng.uniform(-50, 50, (n, 3)); at = frm + rng.uniform(-30, 30, (n, 3)) + 1.0
+    vfov = rng.uniform(20, 100, n); asp = rng.uniform(0.5, 2.5, n)
+    cams = np.zeros((n, 14)); st = rng.random((n, 2)); crays = np.zeros((n, 6))
+    for i in range(n):
+        cams[i] = orc.ref_camera_init(frm[i], at[i], (0, 1, 0), vfov[i], asp[i])
+        crays[i] = orc.ref_camera_get_ray(frm[i], at[i], (0, 1, 0), vfov[i], asp[i], st[i, 0], st[i, 1])
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), frm=frm, at=at, vfov=vfov, asp=asp, cams=cams, st=st, rays=crays)
+
+    # 5. SphereLight / FaceLight::getPosition (light.cpp:76-86,138-190)
+    n = 2000
+    pos = rng.uniform(-5, 5, (n, 3)); rad = rng.uniform(0.1, 2, n)
+    x = pos + rng.normal(0, 1, (n, 3)) * rng.uniform(1.0, 8.0, (n, 1)) * rad[:, None]
+    x[:20] = pos[:20] + np.array([1.0, 0, 0]) * rad[:20, None] * 0.5      # inside the light sphere
+    uv = rng.random((n, 2))
+    sl = np.zeros((n, 7))
+    for i in range(n):
+        p, nl, pdf = orc.ref_sphere_light_sample(pos[i], rad[i], x[i], uv[i, 0], uv[i, 1])
+        sl[i] = (*p, *nl, pdf)
+    nrm = rng.normal(0, 1, (n, 3)); up = rng.normal(0, 1, (n, 3)); wh = rng.uniform(0.5, 5, (n, 2))
+    fl = np.zeros((n, 10))
+    for i in range(n):
+        p, nl, pdf, right = orc.ref_face_light_sample(pos[i], nrm[i], up[i], wh[i, 0], wh[i, 1], uv[i, 0], uv[i, 1])
+        fl[i] = (*p, *nl, pdf, *right)
+    np.savez_compressed(os.path.join(HERE, "lights.npz"), pos=pos, rad=rad, x=x, uv=uv, sl=sl, nrm=nrm, up=up, wh=wh, fl=fl)
+
+    # 6. the reference Octree (insertObject + hit, octree.cpp:61-108,285-376) over triangles
+    for name, ntri, nray, max_size, seed in (("octree_soup_a", 6000, 6000, 128, 5), ("octree_soup_b", 3000, 4000, 16, 6)):
+        tris = scenes.soup(ntri, seed=seed, edge_lo=5e-3, edge_hi=8e-2)
+        tree = orc.RefTree(tris, pad=1e-7, max_size=max_size)
+        rays = rand_rays(np.random.default_rng(seed), nray, -0.5, 1.5, 0.04)
+        prim, t, tests = tree.hit(rays, 0.0, 1e10)
+        prim2, t2, _ = tree.hit(rays, 1e-9, 0.9)
+        st_ = tree.stats()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=seed, ntri=ntri, max_size=max_size,
+                            e=rays["e"], d=rays["d"], prim=prim, t=t, prim_clip=prim2, t_clip=t2, tests=tests,
+                            stats=np.array([st_[k] for k in ("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost")]))
+        tree.close()
+
+    # 7. Group::hit over spheres and planes (Surface.cpp:160-181)
+    desc, cam = scenes.three_sphere_scene("face")
+    objs = np.zeros((len(desc.objects), 6))
+    for i, o in enumerate(desc.objects):
+        objs[i, 0] = o["type"]
+        objs[i, 1:5] = o["p"] if int(o["type"]) == 1 else (o["p"][0], 0, 0, 0)
+    rays = rand_rays(rng, 5000, -6, 8, 0.03)
+    rays["d"] = (rng.uniform(-2.5, 2.5, (5000, 3)) + np.array([0, 1, 0])) - rays["e"]
+    which, t, nrm = orc.ref_group_hit(objs, rays, 1e-9, 1e10)
+    np.savez_compressed(os.path.join(HERE, "group_hit.npz"), e=rays["e"], d=rays["d"], which=which, t=t, normal=nrm)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""The drop-in boundary without a GPU: the C-ABI library loads, exports every symbol that
+include/rt_hip.h declares, its structs have the layout the Python side assumes, host-only
+entry points work, and device entry points fail loudly instead of falling back to the CPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import desc as D
+from raytracer_amd import hip, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rt_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 20
+    L = hip.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in rt_hip.h but not exported"
+    assert set(hip.EXPORTS) == set(names)
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof straight from the C header vs the numpy / ctypes mirrors."""
+    prog = tmp_path / "layout.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "rt_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(rt_object), sizeof(rt_material), sizeof(rt_light), sizeof(rt_mesh),
+         sizeof(rt_scene_desc), sizeof(rt_camera), sizeof(rt_render_params), sizeof(rt_ray));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(rt_object, p), offsetof(rt_material, blur), offsetof(rt_material, nr),
+         offsetof(rt_light, right), offsetof(rt_light, diffuse), offsetof(rt_render_params, seed));
+  printf("%zu %zu %zu\n", offsetof(rt_scene_desc, background), offsetof(rt_scene_desc, tri_box_pad), offsetof(rt_scene_desc, octree_max_depth));
+  return 0; }''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    sizes = [int(x) for x in out[0].split()]
+    assert sizes == [D.OBJECT_DT.itemsize, D.MATERIAL_DT.itemsize, D.LIGHT_DT.itemsize, C.sizeof(D.MeshC),
+                     C.sizeof(D.SceneDescC), C.sizeof(D.CameraC), C.sizeof(D.RenderParamsC), D.RAY_DT.itemsize]
+    offs = [int(x) for x in out[1].split()]
+    assert offs == [D.OBJECT_DT.fields["p"][1], D.MATERIAL_DT.fields["blur"][1], D.MATERIAL_DT.fields["nr"][1],
+                    D.LIGHT_DT.fields["right"][1], D.LIGHT_DT.fields["diffuse"][1], D.RenderParamsC.seed.offset]
+    offs = [int(x) for x in out[2].split()]
+    assert offs == [D.SceneDescC.background.offset, D.SceneDescC.tri_box_pad.offset, D.SceneDescC.octree_max_depth.offset]
+
+
+def test_camera_init_is_host_arithmetic_and_matches_oracle():
+    rng = np.random.default_rng(4)
+    for _ in range(100):
+        frm = rng.uniform(-20, 20, 3); at = frm + rng.uniform(-10, 10, 3) + 0.5
+        a = hip.camera_init(frm, at, (0, 1, 0), rng.uniform(20, 100), 1.5)
+    frm, at = (50, 40, -120), (50, 40, 62)                     # the camera of main.cpp:56
+    a = hip.camera_init(frm, at, (0, 1, 0), 95, 1020 / 630)
+    b = orc.camera_init(frm, at, (0, 1, 0), 95, 1020 / 630)
+    assert bytes(a) == bytes(b)
+
+
+def test_bmp_header_and_payload(tmp_path):
+    """Snapshot (bmpgenerator.cpp:3-45) layout with fixed-width fields."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (6, 8, 3), dtype=np.uint8)
+    f = tmp_path / "t.bmp"
+    hip.save_bmp(img, str(f))
+    raw = f.read_bytes()
+    assert len(raw) == 54 + 6 * 8 * 3 and raw[:2] == b"BM"
+    assert int.from_bytes(raw[2:6], "little") == len(raw) and int.from_bytes(raw[10:14], "little") == 54
+    assert int.from_bytes(raw[14:18], "little") == 40
+    assert int.from_bytes(raw[18:22], "little") == 8 and int.from_bytes(raw[22:26], "little") == 6
+    assert int.from_bytes(raw[26:28], "little") == 1 and int.from_bytes(raw[28:30], "little") == 24
+    assert raw[54:] == img.tobytes()
+    from PIL import Image
+    im = np.asarray(Image.open(str(f)))                       # a standard reader agrees: bottom-up rows, BGR
+    assert np.array_equal(im, img[::-1, :, ::-1])
+
+
+def test_invalid_scenes_are_rejected_before_any_device_work():
+    L = hip.lib()
+    good, _ = scenes.three_sphere_scene()
+    # legacy (non Monte-Carlo) material: not on this path -> error, not a silent fallback
+    bad = D.SceneDesc(good.objects, good.materials.copy(), good.lights, [])
+    bad.materials["type"][0] = D.MAT_NORMAL
+    with pytest.raises(hip.RtError, match="MONTECARLO"):
+        hip.HipScene(bad)
+    bad = D.SceneDesc(good.objects.copy(), good.materials, good.lights, [])
+    bad.objects["material"][1] = 99
+    with pytest.raises(hip.RtError, match="material"):
+        hip.HipScene(bad)
+    bad = D.SceneDesc(good.objects.copy(), good.materials, good.lights, [])
+    bad.objects["type"][0] = D.OBJ_MESH; bad.objects["mesh"][0] = 3
+    with pytest.raises(hip.RtError, match="mesh"):
+        hip.HipScene(bad)
+    bad = D.SceneDesc(good.objects, good.materials, good.lights, [], octree_max_depth=40)
+    with pytest.raises(hip.RtError, match="octree_max_depth"):
+        hip.HipScene(bad)
+    tri = np.zeros((1, 9)); tri[0, 4] = np.nan
+    bad = D.SceneDesc(scenes._stack([scenes.mesh_object(0, 0)], D.OBJECT_DT), good.materials, good.lights, [tri])
+    with pytest.raises(hip.RtError, match="finite"):
+        hip.HipScene(bad)
+    assert L.rt_scene_create(None, None) != 0 and b"null" in L.rt_last_error()
+
+
+def test_no_gpu_means_an_error_not_a_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    good, _ = scenes.three_sphere_scene()
+    with pytest.raises(hip.RtError):
+        hip.HipScene(good)
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under raytracer_amd/ or include/ may import, link or mention the oracle."""
+    bad = []
+    for base in ("raytracer_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".cpp", ".hip", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"\boracle\b|rt_oracle|\borc_", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    out = subprocess.check_output(["ldd", hip.LIB_PATH]).decode()
+    assert "oracle" not in out

@@ -1,0 +1,138 @@
+"""The CPU oracle against the golden vectors captured from the unmodified reference
+(tests/golden/make_golden.py).  Everything here is bit-exact: same fp64 expression order."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import scenes
+from raytracer_amd.desc import LIGHT_DT, LIGHT_FACE, LIGHT_SPHERE, MISS, RAY_DT, OBJECT_DT, MATERIAL_DT, SceneDesc
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_hit_box_bit_exact(golden_dir):
+    g = _load(golden_dir, "hit_box")
+    n = len(g["lo"])
+    nan_cases = 0
+    for i in range(n):
+        h, r0, r1 = orc.hit_box(g["lo"][i], g["hi"][i], g["e"][i], g["d"][i], float(g["t0"][i]), float(g["t1"][i]))
+        eh, e0, e1 = g["out"][i]
+        assert h == int(eh)
+        if h:
+            assert r0 == e0 and r1 == e1
+        nan_cases += int(np.any(g["d"][i] == 0))
+    assert nan_cases > 100          # the zero-direction (inf / NaN) cases really are in there
+
+
+def test_sphere_and_planes_bit_exact(golden_dir):
+    g = _load(golden_dir, "sphere_plane")
+    n = len(g["c"])
+    hits = 0
+    rays = np.zeros(n, RAY_DT); rays["e"] = g["e"]; rays["d"] = g["d"]
+    for i in range(n):
+        h, t = orc.sphere_hit(g["c"][i], float(g["rad"][i]), g["e"][i], g["d"][i], 1e-9, float(g["t1"][i]))
+        assert h == int(g["sph"][i, 0])
+        if h:
+            hits += 1
+            assert t == g["sph"][i, 1]
+        h, t = orc.plane_hit(int(g["kinds"][i]), float(g["coord"][i]), g["e"][i], g["d"][i], 1e-9, float(g["t1"][i]))
+        assert h == int(g["pl"][i, 0])
+        if h:
+            assert t == g["pl"][i, 1]
+    assert hits > 300
+
+
+def test_sphere_normal_through_scene(golden_dir):
+    """Normals stored by Drawable::doAfterHit: one-sphere scenes through the oracle's group path."""
+    g = _load(golden_dir, "sphere_plane")
+    mats = scenes._stack([scenes.material(1, color=(.5, .5, .5))], MATERIAL_DT)
+    for i in range(0, 400):
+        if not g["sph"][i, 0]:
+            continue
+        desc = SceneDesc(scenes._stack([scenes.sphere(g["c"][i], float(g["rad"][i]), 0)], OBJECT_DT), mats, np.zeros(0, LIGHT_DT), [])
+        s = orc.OracleScene(desc)
+        r = np.zeros(1, RAY_DT); r["e"][0] = g["e"][i]; r["d"][0] = g["d"][i]
+        prim, t, nrm, _ = s.trace_rays(r, 1e-9, float(g["t1"][i]))
+        assert prim[0] == 0 and t[0] == g["sph"][i, 1]
+        assert np.array_equal(nrm[0], g["sph"][i, 2:5])
+        s.close()
+
+
+def test_child_bound_bit_exact(golden_dir):
+    g = _load(golden_dir, "child_bound")
+    for i in range(len(g["lo"])):
+        for k in range(8):
+            a, b = orc.child_bound(g["lo"][i], g["hi"][i], k)
+            assert np.array_equal(a, g["out"][i, k, :3]) and np.array_equal(b, g["out"][i, k, 3:])
+
+
+def test_camera_bit_exact(golden_dir):
+    g = _load(golden_dir, "camera")
+    for i in range(len(g["frm"])):
+        cam = orc.camera_init(g["frm"][i], g["at"][i], (0, 1, 0), float(g["vfov"][i]), float(g["asp"][i]))
+        got = np.array(list(cam.e) + list(cam.llc) + list(cam.u) + list(cam.v) + [cam.width, cam.height])
+        assert np.array_equal(got, g["cams"][i])
+        r = orc.camera_get_ray(cam, float(g["st"][i, 0]), float(g["st"][i, 1]))
+        assert np.array_equal(np.concatenate([r["e"], r["d"]]), g["rays"][i])
+
+
+def test_lights_bit_exact(golden_dir):
+    g = _load(golden_dir, "lights")
+    n = len(g["pos"])
+    skipped = 0
+    for i in range(n):
+        l = np.zeros((), LIGHT_DT)
+        l["type"], l["pos"], l["radius"] = LIGHT_SPHERE, g["pos"][i], g["rad"][i]
+        p, nl, pdf = orc.light_sample(l, g["x"][i], float(g["uv"][i, 0]), float(g["uv"][i, 1]))
+        exp = g["sl"][i]
+        if exp[6] > 1e10:                         # "do not sample" sentinel (light.cpp:146-156)
+            skipped += 1
+            assert pdf > 1e10
+            continue
+        if np.isnan(exp).any():                   # shading point inside the light: NaN on both sides
+            assert np.isnan(np.concatenate([p, nl, [pdf]])).any()
+            continue
+        assert np.array_equal(np.concatenate([p, nl, [pdf]]), exp)
+        fl = scenes.face_light(g["pos"][i], g["nrm"][i], g["up"][i], float(g["wh"][i, 0]), float(g["wh"][i, 1]), (1, 1, 1))
+        assert np.array_equal(fl["right"], g["fl"][i, 7:10])          # right = up ^ normal (light.cpp:51)
+        assert np.array_equal(fl["normal"], g["fl"][i, 3:6])          # normalised normal
+        p, nl, pdf = orc.light_sample(fl, g["x"][i], float(g["uv"][i, 0]), float(g["uv"][i, 1]))
+        assert np.array_equal(np.concatenate([p, nl, [pdf]]), g["fl"][i, :7])
+    assert skipped < n // 2
+
+
+@pytest.mark.parametrize("name", ["octree_soup_a", "octree_soup_b"])
+def test_octree_build_and_traversal_bit_exact(golden_dir, name):
+    g = _load(golden_dir, name)
+    tris = scenes.soup(int(g["ntri"]), seed=int(g["seed"]), edge_lo=5e-3, edge_hi=8e-2)
+    desc = SceneDesc(scenes._stack([scenes.mesh_object(0, 0)], OBJECT_DT),
+                     scenes._stack([scenes.material(1, color=(.5, .5, .5))], MATERIAL_DT), np.zeros(0, LIGHT_DT), [tris],
+                     octree_max_size=int(g["max_size"]), octree_max_depth=15)
+    s = orc.OracleScene(desc)
+    st = s.octree_stats(0)
+    assert [st[k] for k in ("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost")] == list(g["stats"])
+    rays = np.zeros(len(g["e"]), RAY_DT); rays["e"] = g["e"]; rays["d"] = g["d"]
+    prim, t, _, cnt = s.trace_rays(rays, 0.0, 1e10)
+    assert np.array_equal(prim, g["prim"]) and np.array_equal(t, g["t"])
+    assert int(cnt[3]) == int(g["tests"])          # same number of primitive tests as the reference made
+    prim, t, _, _ = s.trace_rays(rays, 1e-9, 0.9)
+    assert np.array_equal(prim, g["prim_clip"]) and np.array_equal(t, g["t_clip"])
+    assert (g["prim"] != MISS).sum() > 100
+
+
+def test_group_hit_bit_exact(golden_dir):
+    g = _load(golden_dir, "group_hit")
+    desc, _ = scenes.three_sphere_scene("face")
+    s = orc.OracleScene(desc)
+    rays = np.zeros(len(g["e"]), RAY_DT); rays["e"] = g["e"]; rays["d"] = g["d"]
+    prim, t, nrm, _ = s.trace_rays(rays, 1e-9, 1e10)
+    which = np.where(prim == MISS, -1, prim.astype(np.int64)).astype(np.int32)   # one primitive per object here
+    assert np.array_equal(which, g["which"])
+    hit = which >= 0
+    assert np.array_equal(t[hit], g["t"][hit]) and np.array_equal(nrm[hit], g["normal"][hit])
+    assert hit.sum() > 500

@@ -1,0 +1,113 @@
+"""The CPU oracle against the unmodified reference compiled in this container
+(oracle/_ref/libref_harness.so), on fresh seeded inputs.  Skipped where the reference build is
+absent (the GPU box has no reference checkout; the golden vectors cover that case)."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import scenes
+from raytracer_amd.desc import LIGHT_DT, MATERIAL_DT, MISS, OBJECT_DT, RAY_DT, SceneDesc
+
+pytestmark = pytest.mark.skipif(not orc.ref_available(), reason="oracle/_ref not built (no reference checkout here)")
+
+
+def _rays(rng, n, lo, hi, zero_frac=0.05):
+    r = np.zeros(n, RAY_DT)
+    r["e"] = rng.uniform(lo, hi, (n, 3))
+    d = rng.uniform(0, 1, (n, 3)) - r["e"]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    idx = rng.choice(n, int(n * zero_frac), replace=False)
+    for j, i in enumerate(idx):
+        d[i, j % 3] = 0.0
+    r["d"] = d
+    return r
+
+
+def test_constants():
+    R = orc.ref()
+    assert R.ref_const_zero() == 1e-9 and R.ref_const_infinite() == 1e10 and R.ref_const_pi() == 3.1415926
+
+
+@pytest.mark.parametrize("seed,ntri,max_size,edge", [(11, 20000, 128, (3e-3, 5e-2)), (12, 5000, 8, (1e-2, 1e-1)),
+                                                     (13, 300, 128, (1e-2, 3e-1)), (14, 40000, 64, (1e-3, 2e-2))])
+def test_octree_matches_reference(seed, ntri, max_size, edge):
+    """Tree shape, closest hit (id and t bit-exact) and number of primitive tests."""
+    tris = scenes.soup(ntri, seed=seed, edge_lo=edge[0], edge_hi=edge[1])
+    tree = orc.RefTree(tris, pad=1e-7, max_size=max_size)
+    desc = SceneDesc(scenes._stack([scenes.mesh_object(0, 0)], OBJECT_DT),
+                     scenes._stack([scenes.material(1, color=(.5, .5, .5))], MATERIAL_DT), np.zeros(0, LIGHT_DT), [tris],
+                     octree_max_size=max_size, octree_max_depth=15)
+    s = orc.OracleScene(desc)
+    assert s.octree_stats(0) == tree.stats()
+    rays = _rays(np.random.default_rng(seed), 8000, -0.5, 1.5)
+    for t0, t1 in ((0.0, 1e10), (1e-9, 0.7)):
+        p1, d1, _, cnt = s.trace_rays(rays, t0, t1)
+        p2, d2, tests = tree.hit(rays, t0, t1)
+        assert np.array_equal(p1, p2) and np.array_equal(d1, d2)
+        assert int(cnt[3]) == tests
+    assert (p2 != MISS).sum() > 50
+
+
+def test_cornell_walls_match_reference():
+    """Large axis-aligned triangles (flat boxes, many stay at inner nodes)."""
+    white, _, _ = scenes.cornell_box_meshes(100.0, tess=20)
+    tree = orc.RefTree(white, pad=1e-7, max_size=16)
+    desc = SceneDesc(scenes._stack([scenes.mesh_object(0, 0)], OBJECT_DT),
+                     scenes._stack([scenes.material(1, color=(.5, .5, .5))], MATERIAL_DT), np.zeros(0, LIGHT_DT), [white],
+                     octree_max_size=16, octree_max_depth=15)
+    s = orc.OracleScene(desc)
+    assert s.octree_stats(0) == tree.stats()
+    rng = np.random.default_rng(5)
+    rays = np.zeros(6000, RAY_DT)
+    rays["e"] = rng.uniform(5, 95, (6000, 3))
+    d = rng.normal(0, 1, (6000, 3)); rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    p1, d1, _, _ = s.trace_rays(rays, 1e-9, 1e10)
+    p2, d2, _ = tree.hit(rays, 1e-9, 1e10)
+    assert np.array_equal(p1, p2) and np.array_equal(d1, d2)
+    assert (p1 != MISS).mean() > 0.4        # three of the six box faces are in this mesh
+
+
+def test_primitives_match_reference():
+    rng = np.random.default_rng(21)
+    for _ in range(1500):
+        lo = rng.uniform(-1, 1, 3); hi = lo + rng.uniform(0.01, 2, 3)
+        e = rng.uniform(-3, 3, 3); d = rng.normal(0, 1, 3)
+        if rng.random() < 0.2:
+            d[rng.integers(0, 3)] = 0.0
+        t1 = 1e10 if rng.random() < 0.5 else rng.uniform(0.1, 5)
+        assert orc.hit_box(lo, hi, e, d, 1e-9, t1)[0] == orc.ref_hit_box(lo, hi, e, d, 1e-9, t1)[0]
+        a, b = orc.hit_box(lo, hi, e, d, 1e-9, t1), orc.ref_hit_box(lo, hi, e, d, 1e-9, t1)
+        if a[0]:
+            assert a == b
+        c = rng.uniform(-1, 1, 3); rad = rng.uniform(0.1, 1.5)
+        d2 = (c + rng.normal(0, 0.5, 3) * rad - e) * rng.uniform(0.2, 4)
+        h1, tt1 = orc.sphere_hit(c, rad, e, d2, 1e-9, t1)
+        h2, tt2, _ = orc.ref_sphere_hit(c, rad, e, d2, 1e-9, t1)
+        assert h1 == h2 and (not h1 or tt1 == tt2)
+        kind = int(rng.integers(2, 5)); coord = rng.uniform(-1, 1)
+        h1, tt1 = orc.plane_hit(kind, coord, e, d, 1e-9, t1)
+        h2, tt2, _ = orc.ref_plane_hit(kind, coord, e, d, 1e-9, t1)
+        assert h1 == h2 and (not h1 or tt1 == tt2)
+
+
+def test_camera_and_lights_match_reference():
+    rng = np.random.default_rng(22)
+    for _ in range(300):
+        frm = rng.uniform(-20, 20, 3); at = frm + rng.uniform(-10, 10, 3) + 0.5
+        vfov, asp = rng.uniform(20, 110), rng.uniform(0.4, 3)
+        cam = orc.camera_init(frm, at, (0, 1, 0), vfov, asp)
+        got = np.array(list(cam.e) + list(cam.llc) + list(cam.u) + list(cam.v) + [cam.width, cam.height])
+        assert np.array_equal(got, orc.ref_camera_init(frm, at, (0, 1, 0), vfov, asp))
+        s, t = rng.random(2)
+        r = orc.camera_get_ray(cam, s, t)
+        assert np.array_equal(np.concatenate([r["e"], r["d"]]), orc.ref_camera_get_ray(frm, at, (0, 1, 0), vfov, asp, s, t))
+        pos = rng.uniform(-5, 5, 3); rad = rng.uniform(0.1, 2)
+        x = pos + rng.normal(0, 1, 3) * rng.uniform(1.5, 8) * rad
+        u, v = rng.random(2)
+        l = scenes.sphere_light(pos, rad, (1, 1, 1))
+        p1, n1, pdf1 = orc.light_sample(l, x, u, v)
+        p2, n2, pdf2 = orc.ref_sphere_light_sample(pos, rad, x, u, v)
+        if pdf2 > 1e10 or np.isnan(pdf2):
+            assert pdf1 > 1e10 or np.isnan(pdf1)
+        else:
+            assert np.array_equal(p1, p2) and np.array_equal(n1, n2) and pdf1 == pdf2

@@ -62,7 +62,7 @@ def main():
         print(light, "render 4x4: oracle s %.3f gpu s %.3f" % (to, tg), "rays", k1[0], k2[0], "max rel", rr.max(), "rmse", np.sqrt(((i1 - i2) ** 2).mean()) / 16, flush=True)
 
     # 3. mesh scene
-    desc, cam = scenes.bunny_cornell_scene(nu=48, nv=48)
+    desc, cam = scenes.bunny_cornell_scene(nu=48, nv=48, extras=True)
     so, sg = orc.OracleScene(desc), hip.HipScene(desc)
     print("bunny stats", so.octree_stats(3), sg.octree_stats(3))
     co = orc.camera_init(**cam)
