@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the octree-intersection + path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full frame of the workload: every rank renders its slice of the samples of
+every pixel into a full-frame fp64 radiance buffer (device resident), the buffers are summed
+onto rank 0 (RCCL) and rank 0 resolves the frame to bytes.  At N = 1 the workload is the
+single-GPU benchmark configuration (bunny-class ~69 k triangle mesh in a triangle Cornell box,
+octree leaf capacity 128 as in the reference, 1024 x 1024, 256 spp).  For N > 1 the per-GPU
+work is kept fixed (weak scaling): the frame has 256*N samples per pixel, rank g renders
+sample indices [256 g, 256 (g+1)).
+
+The timed region starts with the scene already uploaded (octree build + upload are one-time
+costs outside it) and contains render + reduce + resolve.  `value` = all rays traced by all
+ranks (camera + bounce + shadow rays, counted on the device) / seconds, in Mrays/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from raytracer_amd import hip, scenes  # noqa: E402
+from raytracer_amd.desc import render_params  # noqa: E402
+from raytracer_amd.parallel import dist_env, sample_slice  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (lane-ops/s, FMA = 1)
+
+
+def algorithmic_bytes(cnt, tri_bytes):
+    """Bytes the closest-hit kernel has to touch for the work it did: one 64-byte node record
+    per node visit (child boxes are derived, not fetched), one triangle record + its 4-byte
+    index per primitive test, 48 bytes of ray in and 16 bytes of hit out per ray."""
+    rays, inner, leaf, prim = (float(x) for x in cnt)
+    return 64.0 * (inner + leaf) + (tri_bytes + 4.0) * prim + (48.0 + 16.0) * rays
+
+
+def algorithmic_lane_ops(cnt):
+    """fp64 lane-operations of the same work: 26 per slab test (node box + 8 children at an
+    inner node, node box at a leaf), 50 per triangle test."""
+    rays, inner, leaf, prim = (float(x) for x in cnt)
+    return 26.0 * 9.0 * inner + 26.0 * leaf + 50.0 * prim
+
+
+def cpu_baseline(desc, cam, W, H, n, m, seed, budget_s=20.0):
+    """The CPU oracle (a port of the reference path) on this box's host cores, on a bounded
+    sample of the same workload: whole image rows spread over the frame, all samples."""
+    from oracle import orc
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    so = orc.OracleScene(desc)
+    c = orc.camera_init(**cam)
+    prm = render_params(W, H, n, m, seed=seed)
+    # calibrate on one row, then take as many evenly spaced rows as fit the budget
+    t0 = time.time()
+    _, k = so.render(c, prm, threads=threads, pix_range=(W * (H // 2), W * (H // 2) + W))
+    dt = time.time() - t0
+    rows = int(max(1, min(H, budget_s / max(dt, 1e-3))))
+    ys = np.unique(np.linspace(0, H - 1, rows).astype(int))
+    rays = 0
+    t0 = time.time()
+    for y in ys:
+        _, k = so.render(c, prm, threads=threads, pix_range=(W * int(y), W * int(y) + W))
+        rays += int(k[0])
+    dt = time.time() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{len(ys)} of {H} image rows (evenly spaced, full {n * m} spp each): {rays} rays in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024, help="image width = height")
+    ap.add_argument("--spp-root", type=int, default=16, help="n of the n x n jitter table per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    a = ap.parse_args()
+
+    rank, local_rank, world = dist_env()
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("for --gpus > 1 launch with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    hip.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W = H = a.size
+    n = a.spp_root
+    m = a.spp_root * world                      # weak scaling: 256 samples per pixel per GPU
+    seed = 1243                                 # the reference's srand value (scene.cpp:22)
+    desc, cam = scenes.bunny_cornell_scene()    # 69 564-triangle mesh, Cornell box of triangle meshes, sphere light
+    ntris = sum(len(x) for x in desc.meshes)
+    t0 = time.time()
+    sc = hip.HipScene(desc)
+    upload_s = time.time() - t0
+    c = hip.camera_init(**cam)
+    b, e = sample_slice(rank, world, n * m)
+    prm = render_params(W, H, n, m, sample_begin=b, sample_end=e, seed=seed)
+
+    img = torch.zeros(H, W, 3, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    bgr = torch.empty(H, W, 3, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        img.zero_()
+        sc.render_dev(c, prm, img.data_ptr(), cnt.data_ptr(), stream)
+        if world > 1:
+            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            hip.resolve_bgr8_dev(img.data_ptr(), W, H, n * m, bgr.data_ptr(), stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    cnt.zero_()
+    sc.set_profiling(True)
+    sc.get_profile(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    sc.check()
+    prof = sc.get_profile()
+    sc.set_profiling(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    total = cnt.clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total = total.cpu().numpy().astype(np.float64)
+    mine = cnt.cpu().numpy().astype(np.float64)
+
+    if rank == 0:
+        steps = max(a.steps, 1)
+        rays_per_step = total[0] / steps
+        paths_per_step = float(W) * H * n * m
+        # dominant kernel: the closest-hit kernel, timed with HIP events around every launch
+        tri_bytes = 72.0
+        launches = max(prof["trace_launches"], 1.0)
+        avg_ms = prof["trace_ms"] / launches
+        bytes_per_launch = algorithmic_bytes(mine, tri_bytes) / launches
+        ops_per_launch = algorithmic_lane_ops(mine) / launches
+        achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved_ops = ops_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("bytes_per_trace_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (whole job; spp/s and roofline fractions alongside)",
+            "value": rays_per_step * steps / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"bunny-class mesh ({ntris} triangles) in a triangle Cornell box via octree (leaf capacity 128), "
+                                   f"{W}x{H} @ {n * n} spp per GPU ({n * m} spp total), sphere light, max depth 40 / roulette from 12",
+                       "width": W, "height": H, "spp_total": n * m, "spp_per_gpu": n * n, "triangles": ntris,
+                       "parallelism": f"spp-partition x{world}, sum-reduce to rank 0"},
+            "spp_per_s": n * m * steps / dt,
+            "mpaths_per_s": paths_per_step * steps / dt / 1e6,
+            "rays_per_path": rays_per_step / paths_per_step,
+            "upload_s": upload_s,
+            "roofline": {"kernel": "rt::k_trace (octree closest hit)", "bound": "hbm",
+                         "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "share_of_step_time": prof["trace_ms"] * 1e-3 / dt},
+            "roofline_valu": {"kernel": "rt::k_trace (octree closest hit)", "bound": "valu-fp64",
+                              "achieved": achieved_ops / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "Tlane-op/s",
+                              "frac": achieved_ops / VALU_FP64_PEAK},
+            "stage_ms_per_step": {"trace": prof["trace_ms"] / steps, "shade": prof["shade_ms"] / steps,
+                                  "rounds": prof["rounds"] / steps},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(desc, cam, W, H, n, m, seed, a.cpu_budget)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

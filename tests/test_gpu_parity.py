@@ -1,0 +1,313 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors.
+
+Bars: hit primitive ids, hit distances, normals and work counters are BIT-EXACT (integer /
+index work and fp64 expressions evaluated in the same order on both sides); radiance is
+compared with a tolerance because the device's sin / cos / exp / pow differ from glibc's in
+the last bits and per-pixel sums are added in a different order: relative error <= 1e-4 per
+path, image RMSE <= 1e-3 (the north-star tolerances), and in practice ~1e-9.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import hip, scenes
+from raytracer_amd.desc import (LIGHT_DT, MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MATERIAL_DT, MISS, OBJECT_DT, RAY_DT,
+                                SceneDesc, render_params)
+
+pytestmark = pytest.mark.gpu
+
+PATH_RTOL = 1e-4      # per-path relative tolerance
+RMSE_TOL = 1e-3       # image RMSE tolerance (radiance units)
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.maximum(1e-9, np.maximum(np.abs(a), np.abs(b)))
+
+
+def _rays(rng, n, lo, hi, zero_frac=0.04):
+    r = np.zeros(n, RAY_DT)
+    r["e"] = rng.uniform(lo, hi, (n, 3))
+    d = rng.uniform(0, 1, (n, 3)) - r["e"]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    idx = rng.choice(n, int(n * zero_frac), replace=False)
+    for j, i in enumerate(idx):
+        d[i, j % 3] = 0.0                 # exact zeros: the slab test divides by them
+    r["d"] = d
+    return r
+
+
+def _camera_rays(cam, W, H):
+    rays = np.zeros(W * H, RAY_DT)
+    for i in range(W * H):
+        rays[i] = orc.camera_get_ray(cam, ((i % W) + .5) / W, ((i // W) + .5) / H)
+    return rays
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _mesh_desc(tris, **kw):
+    return SceneDesc(scenes._stack([scenes.mesh_object(0, 0)], OBJECT_DT),
+                     scenes._stack([scenes.material(MAT_NORMAL, color=(.5, .5, .5))], MATERIAL_DT), np.zeros(0, LIGHT_DT),
+                     [tris], **kw)
+
+
+def test_device_present_and_native_library_loaded():
+    assert hip.device_count() >= 1
+    assert os.path.exists(hip.LIB_PATH)
+
+
+@pytest.mark.parametrize("name", ["octree_soup_a", "octree_soup_b"])
+def test_octree_hits_match_reference_golden(golden_dir, name):
+    """HIP traversal against hits recorded from the reference's own Octree::hit."""
+    g = _load(golden_dir, name)
+    tris = scenes.soup(int(g["ntri"]), seed=int(g["seed"]), edge_lo=5e-3, edge_hi=8e-2)
+    s = hip.HipScene(_mesh_desc(tris, octree_max_size=int(g["max_size"]), octree_max_depth=15))
+    st = s.octree_stats(0)
+    assert [st[k] for k in ("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost")] == list(g["stats"])
+    rays = np.zeros(len(g["e"]), RAY_DT); rays["e"] = g["e"]; rays["d"] = g["d"]
+    prim, t, _, cnt = s.trace_rays(rays, 0.0, 1e10)
+    assert np.array_equal(prim, g["prim"]) and np.array_equal(t, g["t"])
+    assert int(cnt[3]) == int(g["tests"])
+    prim, t, _, _ = s.trace_rays(rays, 1e-9, 0.9)
+    assert np.array_equal(prim, g["prim_clip"]) and np.array_equal(t, g["t_clip"])
+
+
+def test_group_hit_matches_reference_golden(golden_dir):
+    g = _load(golden_dir, "group_hit")
+    desc, _ = scenes.three_sphere_scene("face")
+    s = hip.HipScene(desc)
+    rays = np.zeros(len(g["e"]), RAY_DT); rays["e"] = g["e"]; rays["d"] = g["d"]
+    prim, t, nrm, _ = s.trace_rays(rays, 1e-9, 1e10)
+    which = np.where(prim == MISS, -1, prim.astype(np.int64)).astype(np.int32)
+    assert np.array_equal(which, g["which"])
+    hit = which >= 0
+    assert np.array_equal(t[hit], g["t"][hit]) and np.array_equal(nrm[hit], g["normal"][hit])
+
+
+@pytest.mark.parametrize("seed,ntri,max_size,edge", [(31, 30000, 128, (3e-3, 5e-2)), (32, 4000, 8, (1e-2, 1e-1)),
+                                                     (33, 200, 128, (1e-2, 3e-1)), (34, 60000, 32, (1e-3, 2e-2)),
+                                                     (35, 0, 128, (1e-2, 1e-1)), (36, 1, 128, (2e-1, 5e-1))])
+def test_trace_rays_bit_exact_vs_oracle(seed, ntri, max_size, edge):
+    tris = scenes.soup(ntri, seed=seed, edge_lo=edge[0], edge_hi=edge[1])
+    desc = _mesh_desc(tris, octree_max_size=max_size, octree_max_depth=15)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    assert so.octree_stats(0) == sg.octree_stats(0)
+    rays = _rays(np.random.default_rng(seed), 20000, -0.5, 1.5)
+    for t0, t1 in ((0.0, 1e10), (1e-9, 0.6)):
+        p1, d1, n1, c1 = so.trace_rays(rays, t0, t1)
+        p2, d2, n2, c2 = sg.trace_rays(rays, t0, t1)
+        assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2)
+        assert np.array_equal(c1, c2)         # rays, inner visits, leaf visits, primitive tests
+
+
+def test_primary_id_buffer_bit_exact_small():
+    desc, cam = scenes.soup_scene(50000, seed=9)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    assert bytes(c) == bytes(orc.camera_init(**cam))
+    for W, H in ((640, 360), (37, 21)):       # a ragged size too: not a multiple of the tile
+        a1, b1, k1 = so.trace_primary(c, W, H)
+        a2, b2, k2 = sg.trace_primary(c, W, H)
+        assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(k1, k2)
+        assert (a1 != MISS).sum() > (50 if W > 100 else 0)
+
+
+def test_primary_id_buffer_full_size_properties():
+    """The benchmark-size id buffer (1 M triangles, 3840 x 2160): checked through properties
+    that need no full CPU render -- a random subset of pixels against the oracle (bit-exact),
+    and for EVERY hit pixel the reported t re-derived from the reported triangle alone."""
+    desc, cam = scenes.soup_scene(1_000_000, seed=42)
+    sg = hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    W, H = 3840, 2160
+    prim, t, cnt = sg.trace_primary(c, W, H)
+    assert int(cnt[0]) == W * H
+    hit = prim != MISS
+    assert 0.05 < hit.mean() < 0.95
+    assert np.all(t[~hit] == 1e10) and np.all(t[hit] > 0) and np.all(prim[hit] < 1_000_000)
+    # subset vs oracle
+    so = orc.OracleScene(desc)
+    rng = np.random.default_rng(1)
+    ys, xs = rng.integers(0, H, 20000), rng.integers(0, W, 20000)
+    rays = np.zeros(20000, RAY_DT)
+    for i in range(20000):
+        rays[i] = orc.camera_get_ray(c, (xs[i] + .5) / W, (ys[i] + .5) / H)
+    p1, t1, _, _ = so.trace_rays(rays, 0.0, 1e10)
+    assert np.array_equal(p1, prim[ys, xs]) and np.array_equal(t1, t[ys, xs])
+    # every hit: t equals the single-triangle test of the reported primitive (numpy restatement)
+    tri = desc.meshes[0]
+    yy, xx = np.nonzero(hit)
+    sel = rng.choice(len(yy), 200000, replace=False)
+    yy, xx = yy[sel], xx[sel]
+    s_ = ((0.5 + xx * 1.0) / W).astype(np.float32).astype(np.float64)
+    t_ = ((0.5 + yy * 1.0) / H).astype(np.float32).astype(np.float64)
+    e = np.array(list(c.e)); llc = np.array(list(c.llc)); u = np.array(list(c.u)); v = np.array(list(c.v))
+    look = llc + (u[None] * s_[:, None]) * c.width + (v[None] * t_[:, None]) * c.height
+    d = look - e
+    d = d * (1 / np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]))[:, None]
+    tr = tri[prim[yy, xx]]
+    v0, e1, e2 = tr[:, 0:3], tr[:, 3:6] - tr[:, 0:3], tr[:, 6:9] - tr[:, 0:3]
+    cross = lambda a, b: np.stack([a[:, 1] * b[:, 2] - b[:, 1] * a[:, 2], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - b[:, 0] * a[:, 1]], 1)
+    dot = lambda a, b: a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1] + a[:, 2] * b[:, 2]
+    p = cross(d, e2); det = dot(e1, p); sv = e[None] - v0; q = cross(sv, e1)
+    tt = dot(e2, q) / det
+    assert np.array_equal(tt, t[yy, xx])
+    us = np.where(det < 0, -dot(sv, p), dot(sv, p)); vs = np.where(det < 0, -dot(d, q), dot(d, q))
+    assert np.all((us >= 0) & (vs >= 0) & (us + vs <= np.abs(det)))
+
+
+@pytest.mark.parametrize("light", ["sphere", "face"])
+def test_ray_color_per_path(light):
+    """The getRayColor hook: one radiance value per ray, all three lobes and both light types."""
+    desc, cam = scenes.three_sphere_scene(light)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    W, H = 160, 120
+    rays = _camera_rays(c, W, H)
+    prm = render_params(W, H, 1, seed=77)
+    c1, k1 = so.ray_color(rays, prm)
+    c2, k2 = sg.ray_color(rays, prm)
+    assert np.array_equal(k1, k2)                         # identical path trees: same rays traced
+    r = _rel(c1, c2).max(axis=1)
+    assert (r > PATH_RTOL).mean() <= 1e-4, r.max()
+    assert np.sqrt(((c1 - c2) ** 2).mean()) <= RMSE_TOL
+    assert c1.mean() > 0.05
+    # non-default window and start depth
+    c1, k1 = so.ray_color(rays[:2000], prm, t0=1e-9, t1=9.5, jumptime=5)
+    c2, k2 = sg.ray_color(rays[:2000], prm, t0=1e-9, t1=9.5, jumptime=5)
+    assert np.array_equal(k1, k2) and _rel(c1, c2).max() <= PATH_RTOL
+
+
+@pytest.mark.parametrize("light", ["sphere", "face"])
+def test_render_mesh_scene(light):
+    """Bunny-class mesh in a triangle Cornell box with mirror and glass balls."""
+    desc, cam = scenes.bunny_cornell_scene(nu=40, nv=41, light=light, extras=True)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    for i in range(4):
+        assert so.octree_stats(i) == sg.octree_stats(i)
+    c = hip.camera_init(**cam)
+    W = H = 72
+    a1, b1, _ = so.trace_primary(c, W, H); a2, b2, _ = sg.trace_primary(c, W, H)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    prm = render_params(W, H, 3, seed=9)
+    i1, k1 = so.render(c, prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2)
+    spp = 9
+    assert _rel(i1, i2).max() <= PATH_RTOL
+    assert np.sqrt((((i1 - i2) / spp) ** 2).mean()) <= RMSE_TOL
+    assert (orc.resolve_bgr8(i1, spp) != orc.resolve_bgr8(i2, spp)).mean() < 1e-3   # a last-bit difference may flip a byte
+    assert np.array_equal(hip.resolve_bgr8_host(i2, spp), orc.resolve_bgr8(i2, spp))   # resolve itself is bit-exact
+
+
+def test_render_smallpt_spheres_face_forward():
+    """The nine-sphere box seen from inside its wall spheres (needs the face-forward switch)."""
+    desc, cam = scenes.smallpt_scene()
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    W, H = 64, 48
+    prm = render_params(W, H, 2, seed=4, face_forward=True, max_jump=16)
+    i1, k1 = so.render(c, prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2)
+    assert _rel(i1, i2).max() <= PATH_RTOL and np.sqrt((((i1 - i2) / 4) ** 2).mean()) <= RMSE_TOL
+    off, _ = sg.render(c, render_params(W, H, 2, seed=4, face_forward=False, max_jump=16))
+    assert off.mean() < 0.5 * i2.mean()                   # raw normals: the walls shade black
+
+
+def test_multi_lobe_material_and_blurred_mirror():
+    """Type flags are OR-able and every lobe adds its term (scene.cpp:213,249,267)."""
+    mats = [scenes.material(MAT_NORMAL | MAT_SPECULAR, emission=(.1, .1, .1), color=(.6, .5, .4), blur=0.2),
+            scenes.material(MAT_NORMAL | MAT_TRANSPARENT, color=(.7, .7, .7), atten=(.1, .1, .1), nr=1.3),
+            scenes.material(MAT_NORMAL, color=(.5, .5, .5)), scenes.material(MAT_NORMAL, emission=(9, 9, 9), color=(0, 0, 0))]
+    objs = [scenes.sphere((0, 1, 0), 1.0, 0), scenes.sphere((2.1, 1, 0), 1.0, 1), scenes.plane(2, 0.0, 2),
+            scenes.sphere((0, 5, 1), 0.7, 3)]
+    lights = [scenes.sphere_light((0, 5, 1), 0.7, (9, 9, 9)), scenes.face_light((3, 4, 2), (-1, -1, -1), (0, 1, 0), 1.0, 1.0, (7, 6, 5))]
+    desc = SceneDesc(scenes._stack(objs, OBJECT_DT), scenes._stack(mats, MATERIAL_DT), scenes._stack(lights, LIGHT_DT), [],
+                     background=(.02, .02, .03))
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    c = hip.camera_init((1, 2, 7), (1, 1, 0), (0, 1, 0), 40, 1.0)
+    prm = render_params(48, 48, 2, seed=8, max_jump=14)
+    i1, k1 = so.render(c, prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2) and _rel(i1, i2).max() <= PATH_RTOL
+
+
+def test_sample_slices_accumulate_and_match_whole_frame():
+    """What the multi-GPU sample partition relies on: slices rendered into one buffer add up."""
+    desc, cam = scenes.bunny_cornell_scene(nu=24, nv=25, light="face")
+    sg = hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    W = H = 48
+    whole, k0 = sg.render(c, render_params(W, H, 4, seed=3))
+    buf = np.zeros((H, W, 3))
+    _, k1 = sg.render(c, render_params(W, H, 4, sample_begin=0, sample_end=5, seed=3), buf)
+    _, k2 = sg.render(c, render_params(W, H, 4, sample_begin=5, sample_end=16, seed=3), buf)
+    assert np.allclose(buf, whole, rtol=1e-12, atol=1e-14)
+    assert np.array_equal(k0, k1 + k2)
+    again, _ = sg.render(c, render_params(W, H, 4, seed=3))
+    assert np.allclose(again, whole, rtol=1e-12, atol=1e-14)     # only the atomic add order may differ
+
+
+def test_edge_cases():
+    # empty scene: every ray returns the clear colour, nothing is hit
+    desc = SceneDesc(np.zeros(0, OBJECT_DT), np.zeros(0, MATERIAL_DT), np.zeros(0, LIGHT_DT), [], background=(.25, .5, .75))
+    sg = hip.HipScene(desc)
+    c = hip.camera_init((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 1.0)
+    img, cnt = sg.render(c, render_params(9, 5, 2, seed=1))
+    assert np.array_equal(img, np.tile(np.array([.25, .5, .75]) * 4, (5, 9, 1))) and int(cnt[0]) == 9 * 5 * 4
+    prim, t, _ = sg.trace_primary(c, 9, 5)
+    assert np.all(prim == MISS)
+    # empty batches and empty sample slices
+    out, cnt = sg.ray_color(np.zeros(0, RAY_DT), render_params(1, 1, 1))
+    assert out.shape == (0, 3)
+    img, cnt = sg.render(c, render_params(9, 5, 2, sample_begin=3, sample_end=3))
+    assert not img.any() and int(cnt[0]) == 0
+    # depth limits: max_jump 0 -> clear colour without tracing; rus_jump 0 -> roulette from the first hit
+    desc, cam = scenes.three_sphere_scene("sphere")
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    for kw in (dict(max_jump=0), dict(max_jump=1), dict(max_jump=7, rus_jump=0), dict(max_jump=60, rus_jump=50)):
+        prm = render_params(32, 24, 2, seed=2, **kw)
+        i1, k1 = so.render(c, prm); i2, k2 = sg.render(c, prm)
+        assert np.array_equal(k1, k2) and _rel(i1, i2).max() <= PATH_RTOL, kw
+    # bad parameters are errors
+    with pytest.raises(hip.RtError):
+        sg.render(c, render_params(32, 24, 2, sample_begin=3, sample_end=99))
+    with pytest.raises(hip.RtError):
+        sg.render(c, render_params(32, 24, 2, max_jump=100))
+
+
+def test_camera_inside_mesh_and_axis_aligned_rays():
+    """Rays that start inside the octree's root box and rays with zero direction components."""
+    white, red, green = scenes.cornell_box_meshes(100.0, tess=16)
+    desc = _mesh_desc(np.concatenate([white, red, green]), octree_max_size=16, octree_max_depth=15)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    rng = np.random.default_rng(3)
+    rays = np.zeros(30000, RAY_DT)
+    rays["e"] = rng.uniform(1, 99, (30000, 3))
+    d = rng.normal(0, 1, (30000, 3))
+    d[:3000, 0] = 0; d[3000:6000, 1] = 0; d[6000:8000, (0, 2)] = 0
+    d[8000:9000] = np.sign(d[8000:9000]) * np.array([1, 0, 0])          # exactly along an axis
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["e"][9000:9500] = np.round(rays["e"][9000:9500] / 6.25) * 6.25   # origins on grid planes
+    p1, t1, n1, c1 = so.trace_rays(rays, 1e-9, 1e10)
+    p2, t2, n2, c2 = sg.trace_rays(rays, 1e-9, 1e10)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
+    assert (p1 != MISS).mean() > 0.6
+
+
+def test_profile_counters_are_consistent():
+    desc, cam = scenes.bunny_cornell_scene(nu=24, nv=25)
+    sg = hip.HipScene(desc)
+    sg.set_profiling(True)
+    c = hip.camera_init(**cam)
+    _, cnt = sg.render(c, render_params(64, 64, 2, seed=1))
+    p = sg.get_profile()
+    assert p["trace_launches"] >= 1 and p["trace_ms"] > 0 and p["shade_launches"] == p["trace_launches"]
+    assert int(cnt[0]) > 64 * 64 * 4
