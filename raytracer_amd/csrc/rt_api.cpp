@@ -147,7 +147,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
 
     // one octree per mesh, concatenated into scene-wide arrays
     std::vector<FlatNode> nodes;
-    std::vector<uint32_t> obj_index;
+    std::vector<LeafTri> leaf_tris;
     std::vector<double> tris;
     std::vector<uint32_t> mesh_root(d->nmeshes), mesh_tri_base(d->nmeshes);
     std::vector<uint64_t> mesh_ntris(d->nmeshes);
@@ -159,8 +159,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         std::string err;
         if (!build_octree(m.tris, m.ntris, d->tri_box_pad, max_size, tol, max_depth, ft, err))
             return fail("rt_scene_create: mesh " + std::to_string(mi) + ": " + err);
-        const uint64_t node_base = nodes.size(), idx_base = obj_index.size(), tri_base = tris.size() / 9;
-        if (node_base + ft.nodes.size() >= 0xFFFFFFF0ull || idx_base + ft.obj_index.size() >= 0xFFFFFFF0ull || tri_base + m.ntris >= 0xFFFFFFF0ull)
+        const uint64_t node_base = nodes.size(), idx_base = leaf_tris.size(), tri_base = tris.size() / 9;
+        if (node_base + ft.nodes.size() >= 0xFFFFFFF0ull || idx_base + ft.leaf_tris.size() >= 0xFFFFFFF0ull || tri_base + m.ntris >= 0xFFFFFFF0ull)
             return fail("rt_scene_create: scene too large for 32-bit indices");
         mesh_root[mi] = (uint32_t)node_base;
         mesh_tri_base[mi] = (uint32_t)tri_base;
@@ -170,7 +170,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
             f.obj_begin += (uint32_t)idx_base;
             nodes.push_back(f);
         }
-        for (uint32_t t : ft.obj_index) obj_index.push_back(t + (uint32_t)tri_base);
+        for (LeafTri t : ft.leaf_tris) { t.id += (uint32_t)tri_base; leaf_tris.push_back(t); }
         tris.insert(tris.end(), ft.tri_rec.begin(), ft.tri_rec.end());
         std::memcpy(infos[mi].stats, ft.stats, sizeof ft.stats);
     }
@@ -213,7 +213,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         e = upload(vec, dst);
         if (*dst) s->allocs.push_back(*dst);
     };
-    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(obj_index, &p_idx); up(tris, &p_tris);
+    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tris, &p_tris);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
     if (e != hipSuccess) { rt_scene_destroy(s); return fail_hip("scene upload", e); }
@@ -221,7 +221,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.materials = (const rt_material *)p_mat;
     s->dev.lights = (const rt_light *)p_light;
     s->dev.nodes = (const FlatNode *)p_nodes;
-    s->dev.obj_index = (const uint32_t *)p_idx;
+    s->dev.leaf_tris = (const LeafTri *)p_idx;
     s->dev.tris = (const double *)p_tris;
     s->dev.nobjects = (int32_t)d->nobjects;
     s->dev.nlights = (int32_t)d->nlights;
@@ -250,9 +250,9 @@ int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double
 {
     if (!s) return fail("rt_trace_rays: null scene");
     if (n && (!rays || !prim_id)) return fail("rt_trace_rays: null buffer");
-    if (n > 0xFFFFFFFFull * 128) return fail("rt_trace_rays: batch too large");
+    if (n >= 0xFFFFFFFFull) return fail("rt_trace_rays: batch too large");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_rays(s->dev, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 2, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -262,7 +262,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *
     if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail("rt_trace_primary: bad image size");
     if (!prim_id) return fail("rt_trace_primary: null buffer");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_primary(s->dev, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 2, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -334,7 +334,7 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
         const uint64_t base = count[src] - c;
         HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 4, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
-        HIP_TRY(launch_trace(s->dev, A, s->stack[src], base, (uint32_t)c, st));
+        HIP_TRY(launch_trace(s->dev, s->num_cu, s->d_ctrl + 1, A, s->stack[src], base, (uint32_t)c, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
         HIP_TRY(launch_shade(s->dev, A, s->stack[src], base, (uint32_t)c, s->stack[dst], count[dst], s->d_ctrl, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));

@@ -24,8 +24,8 @@ struct DevScene {
     const rt_material *materials;
     const rt_light    *lights;
     const FlatNode    *nodes;      // all meshes' nodes, 64-byte records
-    const uint32_t    *obj_index;  // per-node triangle lists (global triangle record indices)
-    const double      *tris;       // triangle records: v0, e1, e2 (9 doubles)
+    const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
+    const double      *tris;       // v0, e1, e2 (9 doubles) by global triangle index, for shading normals
     int32_t nobjects;
     int32_t nlights;
     double  background[3];

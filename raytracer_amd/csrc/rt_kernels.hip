@@ -126,13 +126,27 @@ __device__ __forceinline__ bool hit_box(const double *lo, const double *hi, V3 e
 
 struct Counters { uint32_t rays, inner, leaf, prim; };
 
-// Two-sided Moeller-Trumbore on the stored (v0, e1, e2) record; the octree payload test that
-// stands where BoxNode::calHit does in the reference (Surface.cpp:43-59).  The barycentric
-// tests compare the un-normalised numerators with |det| (sign flips are exact), so a division
-// is only spent on rays that pass them.
-__device__ __forceinline__ bool tri_hit(const double *tr, V3 e, V3 d, double t0, double t1, double &tout)
+// One 80-byte triangle record in registers.
+struct TriReg { double v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z; uint32_t id; };
+__device__ __forceinline__ TriReg tri_load(const LeafTri *p)
 {
-    V3 v0 = ld3(tr), e1 = ld3(tr + 3), e2 = ld3(tr + 6);
+    // five 16-byte loads
+    const double2 *q = reinterpret_cast<const double2 *>(p);
+    const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+    const double2 e = q[4];
+    TriReg r;
+    r.v0x = a.x; r.v0y = a.y; r.v0z = b.x; r.e1x = b.y; r.e1y = c.x; r.e1z = c.y; r.e2x = d.x; r.e2y = d.y; r.e2z = e.x;
+    r.id = (uint32_t)(unsigned long long)__double_as_longlong(e.y);
+    return r;
+}
+
+// Two-sided Moeller-Trumbore on a (v0, e1, e2) record; the octree payload test that stands
+// where BoxNode::calHit does in the reference (Surface.cpp:43-59).  The barycentric tests
+// compare the un-normalised numerators with |det| (sign flips are exact), so a division is
+// only spent on rays that pass them.
+__device__ __forceinline__ bool tri_hit(const TriReg &tr, V3 e, V3 d, double t0, double t1, double &tout)
+{
+    V3 v0 = mk(tr.v0x, tr.v0y, tr.v0z), e1 = mk(tr.e1x, tr.e1y, tr.e1z), e2 = mk(tr.e2x, tr.e2y, tr.e2z);
     V3 p = cross(d, e2);
     double det = dot(e1, p);
     double a = fabs(det);
@@ -149,131 +163,6 @@ __device__ __forceinline__ bool tri_hit(const double *tr, V3 e, V3 d, double t0,
     if (!(t >= t0 && t <= t1)) return false;
     tout = t;
     return true;
-}
-
-// Octree::hit (octree.cpp:285-376): ordered depth-first search.  Per open inner node the LDS
-// stack keeps {child_base, visiting order (8 x 3 bits) | count << 24 | next << 28}.
-// The reference re-checks `minrec.t < next.t` before descending (octree.cpp:359); next.t is
-// the child's own slab entry distance, which the child visit recomputes bit-identically, so
-// the check is made there.
-template <int BLOCK>
-__device__ inline bool octree_hit(const DevScene &S, uint32_t root, V3 e, V3 d, double t0, double t1,
-                                  double &tout, uint32_t &pout, uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
-{
-    const int tid = threadIdx.x;
-    double mint = t1 + 1;
-    uint32_t minprim = RT_MISS;
-    int sp = 0;
-    uint32_t cur = root;
-    bool have = true;
-    for (;;) {
-        if (have) {
-            const FlatNode *nd = S.nodes + cur;
-            double lo[3] = { nd->lo[0], nd->lo[1], nd->lo[2] };
-            double hi[3] = { nd->hi[0], nd->hi[1], nd->hi[2] };
-            const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count;
-            // per-axis plane distances; the node's own slab test and all 8 child tests use them
-            double alo[3], ahi[3];
-            alo[0] = (lo[0] - e.x) / d.x; alo[1] = (lo[1] - e.y) / d.y; alo[2] = (lo[2] - e.z) / d.z;
-            ahi[0] = (hi[0] - e.x) / d.x; ahi[1] = (hi[1] - e.y) / d.y; ahi[2] = (hi[2] - e.z) / d.z;
-            double bt0 = smin(alo[0], ahi[0]), bt1 = smax(alo[0], ahi[0]);
-            double m;
-            m = smin(alo[1], ahi[1]); if (bt0 < m) bt0 = m;
-            m = smin(alo[2], ahi[2]); if (bt0 < m) bt0 = m;
-            if (bt0 < t0) bt0 = t0;
-            m = smax(alo[1], ahi[1]); if (m < bt1) bt1 = m;
-            m = smax(alo[2], ahi[2]); if (m < bt1) bt1 = m;
-            if (t1 < bt1) bt1 = t1;
-            const bool hb = bt0 <= bt1;
-            if (cur == root) {
-                if (!hb) return false;                       // octree.cpp:291
-            } else if (mint < bt0) {
-                break;                                       // octree.cpp:359-361
-            }
-            if (child_base) c.inner++; else c.leaf++;
-            bool improved = false;
-            if (hb) {                                        // OctreeNode::hit, octree.cpp:19-38
-                double tempt = bt1, best = 0;
-                uint32_t bprim = RT_MISS;
-                for (uint32_t k = 0; k < obj_count; k++) {
-                    uint32_t ti = S.obj_index[obj_begin + k];
-                    double tt;
-                    c.prim++;
-                    if (tri_hit(S.tris + 9ull * ti, e, d, bt0, bt1, tt)) {
-                        if (tt <= tempt) { tempt = tt; best = tt; bprim = ti; }
-                    }
-                }
-                if (bprim != RT_MISS && best < mint) { mint = best; minprim = bprim; improved = true; }
-            }
-            have = false;
-            if (!child_base) {
-                if (improved) break;                         // octree.cpp:326-329
-            } else {
-                // 8 child slab tests (octree.cpp:337-343) from {lo, mid, hi} plane distances
-                double amid[3];
-                amid[0] = ((lo[0] + hi[0]) / 2 - e.x) / d.x;
-                amid[1] = ((lo[1] + hi[1]) / 2 - e.y) / d.y;
-                amid[2] = ((lo[2] + hi[2]) / 2 - e.z) / d.z;
-                double mnL[3], mxL[3], mnH[3], mxH[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    mnL[k] = smin(alo[k], amid[k]); mxL[k] = smax(alo[k], amid[k]);
-                    mnH[k] = smin(amid[k], ahi[k]); mxH[k] = smax(amid[k], ahi[k]);
-                }
-                double ct[8];
-                uint32_t hitmask = 0;
-#pragma unroll
-                for (int ci = 0; ci < 8; ci++) {
-                    // corner order of getChildBound: x-half, y-half, z-half of child ci
-                    const int hx = (ci == 1 || ci == 2 || ci == 5 || ci == 6), hy = (ci == 2 || ci == 3 || ci == 6 || ci == 7), hz = ci >> 2;
-                    double r0 = hx ? mnH[0] : mnL[0], r1 = hx ? mxH[0] : mxL[0];
-                    double q;
-                    q = hy ? mnH[1] : mnL[1]; if (r0 < q) r0 = q;
-                    q = hz ? mnH[2] : mnL[2]; if (r0 < q) r0 = q;
-                    if (r0 < t0) r0 = t0;
-                    q = hy ? mxH[1] : mxL[1]; if (q < r1) r1 = q;
-                    q = hz ? mxH[2] : mxL[2]; if (q < r1) r1 = q;
-                    if (t1 < r1) r1 = t1;
-                    ct[ci] = r0;
-                    if (r0 <= r1) hitmask |= 1u << ci;
-                }
-                // std::sort by entry distance (octree.cpp:344); equal keys keep child order
-                uint32_t order = 0, cnt = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (hitmask & (1u << i)) {
-                        uint32_t rank = 0;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            if (j == i) continue;
-                            if (hitmask & (1u << j)) {
-                                bool before = (j < i) ? !(ct[i] < ct[j]) : (ct[j] < ct[i]);
-                                rank += before ? 1u : 0u;
-                            }
-                        }
-                        order |= (uint32_t)i << (3 * rank);
-                        cnt++;
-                    }
-                }
-                if (cnt) {
-                    stk[0][sp][tid] = child_base;
-                    stk[1][sp][tid] = order | (cnt << 24);
-                    sp++;
-                }
-            }
-        } else {
-            if (sp == 0) break;
-            uint32_t w = stk[1][sp - 1][tid];
-            uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
-            if (pos == cnt) { sp--; continue; }
-            uint32_t child = (w >> (3 * pos)) & 7u;
-            stk[1][sp - 1][tid] = w + (1u << 28);
-            cur = stk[0][sp - 1][tid] + child;
-            have = true;
-        }
-    }
-    if (mint <= t1 && minprim != RT_MISS) { tout = mint; pout = minprim; return true; }
-    return false;
 }
 
 // Sphere::hit, Surface.cpp:73-111 (the tangent branch skips the [t0,t1] window)
@@ -317,23 +206,291 @@ __device__ __forceinline__ bool plane_hit(int type, double coord, V3 e, V3 d, do
 
 struct Hit { double t; int32_t obj; uint32_t prim; };
 
-// Group::hit, Surface.cpp:160-181: every child is tested, each hit shrinks t1
-template <int BLOCK>
-__device__ inline bool group_hit(const DevScene &S, V3 e, V3 d, double t0, double t1, Hit &h,
-                                 uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+// ------------------------------------------------------------------ the closest-hit engine
+// group_->calHit(ray, t0, t1, &rec) for a stream of rays: Group::hit (Surface.cpp:160-181)
+// walks the scene's objects in order, every hit shrinking t1; a mesh object runs Octree::hit
+// (octree.cpp:285-376), the ordered depth-first search, on its flattened tree.
+//
+// The engine is written for a 64-wide wave whose lanes follow DIFFERENT rays.  Each lane is a
+// small state machine:
+//     FETCH  take the next ray of the launch (persistent lanes: a lane that finishes its ray
+//            takes another one; the lanes of a wave that need rays get consecutive indices
+//            from one atomic, ballot + popcount)
+//     OBJ    advance through the object list; spheres and planes are tested on the spot, a mesh
+//            opens its octree root
+//     NODE / POP   open an octree node / pop the next child from the LDS stack and open it
+//     TRI    walk the triangle run of the opened node, one triangle per step
+// and the wave executes one KIND of step at a time, chosen so that most lanes take part: steps
+// that fetch / open nodes are held back until enough lanes want one (or nobody has triangles
+// left).  Without this a wave would run at the pace of its longest ray and its longest leaf.
+//
+// Per open inner node the LDS stack keeps {child_base, visiting order (8 x 3 bits) |
+// count << 24 | next << 28}.  The reference re-checks `minrec.t < next.t` before descending
+// (octree.cpp:359); next.t is the child's own slab entry distance, which the child visit
+// recomputes bit-identically, so the check is made there.  The child list of an inner node is
+// computed before its own triangles are tested (the reference does it after, octree.cpp:320-344);
+// the list does not depend on those tests, so the visit order is unchanged.
+//
+// FAST node steps (every participating ray has all direction components far from zero): a/d
+// is formed from the ray's correctly rounded reciprocals and two fused multiply-adds
+// (q0 = a*r; q = fma(fma(-q0,d,a),r,q0)), which reproduces the IEEE quotient, and no NaN can
+// appear in the slab arithmetic, so fmin / fmax equal std::min / std::max.  Otherwise true
+// divisions and the literal comparison forms are used (zero components give the +-inf / NaN
+// cases of hitBox, algorithms.h:208-236).
+enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 5 };
+enum { NODE_MIN = 16, OBJ_MIN = 16 };
+
+template <bool FAST> __device__ __forceinline__ double tmin2(double a, double b) { return FAST ? fmin(a, b) : smin(a, b); }
+template <bool FAST> __device__ __forceinline__ double tmax2(double a, double b) { return FAST ? fmax(a, b) : smax(a, b); }
+template <bool FAST> __device__ __forceinline__ double qdiv(double a, double d, double r)
 {
-    bool flag = false;
-    c.rays++;
-    for (int i = 0; i < S.nobjects; i++) {
-        const DevObject &o = S.objects[i];
-        double t; uint32_t prim = 0;
-        bool hit;
-        if (o.type == RT_OBJ_SPHERE) hit = sphere_hit(o.p, e, d, t0, t1, t);
-        else if (o.type == RT_OBJ_MESH) hit = octree_hit<BLOCK>(S, o.root, e, d, t0, t1, t, prim, stk, c);
-        else hit = plane_hit(o.type, o.p[0], e, d, t0, t1, t);
-        if (hit) { flag = true; t1 = t; h.t = t; h.obj = i; h.prim = prim; }
+    if (FAST) {
+        double q0 = a * r;
+        double rem = __builtin_fma(-q0, d, a);
+        return __builtin_fma(rem, r, q0);
     }
-    return flag;
+    return a / d;
+}
+__device__ __forceinline__ bool dir_is_regular(V3 d)
+{
+    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    return ax >= 1e-150 && ax <= 1e150 && ay >= 1e-150 && ay <= 1e150 && az >= 1e-150 && az <= 1e150;
+}
+
+struct TravState {
+    // ray
+    V3 e, d, r;
+    double t0, t1;          // t1 shrinks with every object hit (Surface.cpp:168,175)
+    uint32_t item;          // index of the ray in its source
+    int32_t hobj; uint32_t hprim;
+    int32_t oi;             // object being processed
+    bool fast;
+    // octree
+    double mint; uint32_t minprim;
+    int sp; uint32_t cur, root;
+    // triangle run
+    uint32_t k, kend, bprim;
+    double bt0, bt1, tempt, best;
+    bool leaf;
+};
+
+template <bool FAST, int BLOCK>
+__device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode, TriReg &nxt,
+                                          uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+{
+    const int tid = threadIdx.x;
+    const V3 e = T.e, d = T.d, r = T.r;
+    const double t0 = T.t0, t1 = T.t1;
+    const FlatNode *nd = S.nodes + T.cur;
+    const double lo0 = nd->lo[0], lo1 = nd->lo[1], lo2 = nd->lo[2];
+    const double hi0 = nd->hi[0], hi1 = nd->hi[1], hi2 = nd->hi[2];
+    const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count;
+    // per-axis plane distances; the node's own slab test and all 8 child tests use them
+    const double al0 = qdiv<FAST>(lo0 - e.x, d.x, r.x), al1 = qdiv<FAST>(lo1 - e.y, d.y, r.y), al2 = qdiv<FAST>(lo2 - e.z, d.z, r.z);
+    const double ah0 = qdiv<FAST>(hi0 - e.x, d.x, r.x), ah1 = qdiv<FAST>(hi1 - e.y, d.y, r.y), ah2 = qdiv<FAST>(hi2 - e.z, d.z, r.z);
+    double n0 = tmin2<FAST>(al0, ah0), n1 = tmax2<FAST>(al0, ah0);             // hitBox, algorithms.h:223-236
+    if (FAST) {
+        n0 = fmax(fmax(n0, fmin(al1, ah1)), fmax(fmin(al2, ah2), t0));
+        n1 = fmin(fmin(n1, fmax(al1, ah1)), fmin(fmax(al2, ah2), t1));
+    } else {
+        double m;
+        m = smin(al1, ah1); if (n0 < m) n0 = m;
+        m = smin(al2, ah2); if (n0 < m) n0 = m;
+        if (n0 < t0) n0 = t0;
+        m = smax(al1, ah1); if (m < n1) n1 = m;
+        m = smax(al2, ah2); if (m < n1) n1 = m;
+        if (t1 < n1) n1 = t1;
+    }
+    const bool hb = n0 <= n1;
+    mode = TM_POP;
+    if (T.cur == T.root ? !hb : (T.mint < n0)) {           // octree.cpp:291 / octree.cpp:359-361
+        mode = TM_OBJ;                                     // this octree is finished
+        return;
+    }
+#ifndef RT_STEP_STATS
+    if (child_base) c.inner++; else c.leaf++;
+#endif
+    if (child_base) {
+        // 8 child slab tests (octree.cpp:337-343) from the {lo, mid, hi} plane distances
+        const double am0 = qdiv<FAST>((lo0 + hi0) / 2 - e.x, d.x, r.x);
+        const double am1 = qdiv<FAST>((lo1 + hi1) / 2 - e.y, d.y, r.y);
+        const double am2 = qdiv<FAST>((lo2 + hi2) / 2 - e.z, d.z, r.z);
+        const double mnL[3] = { tmin2<FAST>(al0, am0), tmin2<FAST>(al1, am1), tmin2<FAST>(al2, am2) };
+        const double mxL[3] = { tmax2<FAST>(al0, am0), tmax2<FAST>(al1, am1), tmax2<FAST>(al2, am2) };
+        const double mnH[3] = { tmin2<FAST>(am0, ah0), tmin2<FAST>(am1, ah1), tmin2<FAST>(am2, ah2) };
+        const double mxH[3] = { tmax2<FAST>(am0, ah0), tmax2<FAST>(am1, ah1), tmax2<FAST>(am2, ah2) };
+        double ct[8];
+        uint32_t hitmask = 0;
+#pragma unroll
+        for (int ci = 0; ci < 8; ci++) {
+            // corner order of getChildBound: x-half, y-half, z-half of child ci
+            const int hx = (ci == 1 || ci == 2 || ci == 5 || ci == 6), hy = (ci == 2 || ci == 3 || ci == 6 || ci == 7), hz = ci >> 2;
+            double r0, r1;
+            if (FAST) {
+                r0 = fmax(fmax(hx ? mnH[0] : mnL[0], hy ? mnH[1] : mnL[1]), fmax(hz ? mnH[2] : mnL[2], t0));
+                r1 = fmin(fmin(hx ? mxH[0] : mxL[0], hy ? mxH[1] : mxL[1]), fmin(hz ? mxH[2] : mxL[2], t1));
+            } else {
+                double q;
+                r0 = hx ? mnH[0] : mnL[0]; r1 = hx ? mxH[0] : mxL[0];
+                q = hy ? mnH[1] : mnL[1]; if (r0 < q) r0 = q;
+                q = hz ? mnH[2] : mnL[2]; if (r0 < q) r0 = q;
+                if (r0 < t0) r0 = t0;
+                q = hy ? mxH[1] : mxL[1]; if (q < r1) r1 = q;
+                q = hz ? mxH[2] : mxL[2]; if (q < r1) r1 = q;
+                if (t1 < r1) r1 = t1;
+            }
+            ct[ci] = r0;
+            if (r0 <= r1) hitmask |= 1u << ci;
+        }
+        // std::sort by entry distance (octree.cpp:344); equal keys keep child order
+        uint32_t order = 0, cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t rank = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (j == i) continue;
+                const bool before = (j < i) ? !(ct[i] < ct[j]) : (ct[j] < ct[i]);
+                rank += (before && (hitmask >> j & 1u)) ? 1u : 0u;
+            }
+            if (hitmask >> i & 1u) { order |= (uint32_t)i << (3 * rank); cnt++; }
+        }
+        if (cnt) {
+            stk[0][T.sp][tid] = child_base;
+            stk[1][T.sp][tid] = order | (cnt << 24);
+            T.sp++;
+        }
+    }
+    if (hb && obj_count) {                                  // OctreeNode::hit, octree.cpp:19-38
+        mode = TM_TRI;
+        T.k = obj_begin; T.kend = obj_begin + obj_count;
+        T.bt0 = n0; T.bt1 = n1; T.tempt = n1; T.bprim = RT_MISS;
+        T.leaf = child_base == 0;
+        nxt = tri_load(S.leaf_tris + T.k);
+    }
+}
+
+// Src supplies the rays of one launch:
+//   uint32_t count() const;
+//   bool load(uint32_t item, V3 &e, V3 &d, double &t0, double &t1) const;  // false: nothing to trace
+//   void store(uint32_t item, bool hit, const Hit &h) const;
+// `next` is a zero-initialised device counter shared by the launch.
+template <int BLOCK, class Src>
+__device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t *next,
+                                    uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+{
+    const int tid = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total = src.count();
+    TravState T = {};
+    TriReg nxt = {};
+    int mode = TM_FETCH;
+    for (;;) {
+        const unsigned long long mO = __ballot(mode == TM_FETCH || mode == TM_OBJ);
+        const unsigned long long mN = __ballot(mode == TM_NODE || mode == TM_POP);
+        const unsigned long long mT = __ballot(mode == TM_TRI);
+        if ((mO | mN | mT) == 0ull) break;
+        if (mO != 0ull && ((mN | mT) == 0ull || __popcll(mO) >= OBJ_MIN)) {
+#ifdef RT_STEP_STATS
+            c.rays += 1; if (mode == TM_FETCH || mode == TM_OBJ) c.rays += 1u << 16;
+#endif
+            // ------------------------------------------------------------ fetch / object step
+            if (mode == TM_OBJ && T.oi >= 0) {
+                // an octree just finished for object T.oi: Octree::hit's verdict (octree.cpp:371-375)
+                if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
+                T.minprim = RT_MISS;
+            }
+            const unsigned long long need = __ballot(mode == TM_FETCH);
+            if (mode == TM_FETCH) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(need));
+                base = __shfl(base, (int)leader, 64);
+                const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (item >= total) {
+                    mode = TM_EXIT;
+                } else {
+                    T.item = item;
+                    T.hobj = -1; T.hprim = 0; T.oi = -1; T.minprim = RT_MISS;
+                    if (src.load(item, T.e, T.d, T.t0, T.t1)) {
+#ifndef RT_STEP_STATS
+                        c.rays++;
+#endif
+                        T.fast = dir_is_regular(T.d);
+                        T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                        mode = TM_OBJ;
+                    } else {
+                        Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0;
+                        src.store(item, false, h);          // stays in FETCH
+                    }
+                }
+            }
+            if (mode == TM_OBJ) {
+                // Group::hit, Surface.cpp:160-181: objects in order until the next mesh
+                for (;;) {
+                    T.oi++;
+                    if (T.oi >= S.nobjects) {
+                        Hit h; h.t = T.t1; h.obj = T.hobj; h.prim = T.hprim;
+                        src.store(T.item, T.hobj >= 0, h);
+                        mode = TM_FETCH;
+                        break;
+                    }
+                    const DevObject &o = S.objects[T.oi];
+                    if (o.type == RT_OBJ_MESH) {
+                        T.root = o.root; T.cur = o.root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS;   // octree.cpp:312-313
+                        mode = TM_NODE;
+                        break;
+                    }
+                    double t;
+                    const bool hit = (o.type == RT_OBJ_SPHERE) ? sphere_hit(o.p, T.e, T.d, T.t0, T.t1, t)
+                                                               : plane_hit(o.type, o.p[0], T.e, T.d, T.t0, T.t1, t);
+                    if (hit) { T.t1 = t; T.hobj = T.oi; T.hprim = 0; }
+                }
+            }
+            continue;
+        }
+        if (mN != 0ull && (mT == 0ull || __popcll(mN) >= NODE_MIN)) {
+#ifdef RT_STEP_STATS
+            c.inner += 1; if (mode == TM_NODE || mode == TM_POP) c.leaf += 1;
+#endif
+            // ------------------------------------------------------------ node step
+            if (mode == TM_POP) {
+                mode = TM_OBJ;                               // empty stack: this octree is finished
+                while (T.sp > 0) {
+                    const uint32_t w = stk[1][T.sp - 1][tid];
+                    const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
+                    if (pos == cnt) { T.sp--; continue; }
+                    stk[1][T.sp - 1][tid] = w + (1u << 28);
+                    T.cur = stk[0][T.sp - 1][tid] + ((w >> (3 * pos)) & 7u);
+                    mode = TM_NODE;
+                    break;
+                }
+            }
+            const bool in = mode == TM_NODE;
+            if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, nxt, stk, c); }
+            else { if (in) node_step<false, BLOCK>(S, T, mode, nxt, stk, c); }
+            continue;
+        }
+        // ---------------------------------------------------------------- triangle step
+#ifdef RT_STEP_STATS
+        c.prim += 1u << 16;
+#endif
+        if (mode == TM_TRI) {
+            const TriReg tr = nxt;
+            T.k++;
+            if (T.k < T.kend) nxt = tri_load(S.leaf_tris + T.k);
+            c.prim++;
+            double tt;
+            if (tri_hit(tr, T.e, T.d, T.bt0, T.bt1, tt)) {
+                if (tt <= T.tempt) { T.tempt = tt; T.best = tt; T.bprim = tr.id; }   // last equal wins, octree.cpp:31
+            }
+            if (T.k == T.kend) {
+                bool improved = false;
+                if (T.bprim != RT_MISS && T.best < T.mint) { T.mint = T.best; T.minprim = T.bprim; improved = true; }   // octree.cpp:320-325
+                mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
+            }
+        }
+    }
 }
 
 // Drawable::doAfterHit -> getRawNormal (Surface.cpp:228-231, 68-71; Surface.h:184,197,211);
@@ -375,52 +532,74 @@ __device__ inline void flush_counters(uint64_t *counters, const Counters &c)
     }
 }
 
-// ------------------------------------------------------------------ closest-hit kernels
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(DevScene S, const rt_ray *rays, uint64_t n, double t0, double t1,
-                                                          uint32_t *prim_id, double *tout, double *normal, uint64_t *counters)
+// Pixel enumeration: 8 x 8 tiles over the part of the image that whole tiles cover, then the
+// right and top remainders row by row (a bijection on [0, W*H) for any size).
+__device__ __forceinline__ void work_pixel(uint32_t idx, int W, int H, int &x, int &y)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    uint64_t i = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
-    Counters c = { 0, 0, 0, 0 };
-    if (i < n) {
-        V3 e = ld3(rays[i].e), d = ld3(rays[i].d);
-        Hit h;
-        if (group_hit<RT_BLOCK>(S, e, d, t0, t1, h, stk, c)) {
-            prim_id[i] = global_prim(S, h);
-            if (tout) tout[i] = h.t;
-            if (normal) { V3 nn = hit_normal(S, h, e + d * h.t); normal[3 * i] = nn.x; normal[3 * i + 1] = nn.y; normal[3 * i + 2] = nn.z; }
-        } else {
-            prim_id[i] = RT_MISS;
-            if (tout) tout[i] = RT_INFINITE;
-            if (normal) { normal[3 * i] = 0; normal[3 * i + 1] = 0; normal[3 * i + 2] = 0; }
+    const uint32_t Wt = (uint32_t)W & ~7u, Ht = (uint32_t)H & ~7u;
+    const uint32_t tiled = Wt * Ht;
+    if (idx < tiled) {
+        const uint32_t tile = idx >> 6, l = idx & 63u, tx = Wt >> 3;
+        x = (int)((tile % tx) * 8 + (l & 7u));
+        y = (int)((tile / tx) * 8 + (l >> 3));
+        return;
+    }
+    idx -= tiled;
+    const uint32_t rw = (uint32_t)W - Wt;
+    if (idx < rw * (uint32_t)H) { x = (int)(Wt + idx % rw); y = (int)(idx / rw); return; }
+    idx -= rw * (uint32_t)H;
+    x = (int)(idx % Wt); y = (int)(Ht + idx / Wt);
+}
+
+// ------------------------------------------------------------------ closest-hit kernels
+struct RaySrc {             // rt_trace_rays: caller's ray array
+    DevScene S; const rt_ray *rays; uint32_t n; double t0, t1; uint32_t *prim_id; double *tout; double *normal;
+    __device__ uint32_t count() const { return n; }
+    __device__ bool load(uint32_t i, V3 &e, V3 &d, double &a, double &b) const { e = ld3(rays[i].e); d = ld3(rays[i].d); a = t0; b = t1; return true; }
+    __device__ void store(uint32_t i, bool hit, const Hit &h) const
+    {
+        prim_id[i] = hit ? global_prim(S, h) : RT_MISS;
+        if (tout) tout[i] = hit ? h.t : RT_INFINITE;
+        if (normal) {
+            V3 nn = mk(0, 0, 0);
+            if (hit) nn = hit_normal(S, h, ld3(rays[i].e) + ld3(rays[i].d) * h.t);
+            normal[3ull * i] = nn.x; normal[3ull * i + 1] = nn.y; normal[3ull * i + 2] = nn.z;
         }
     }
+};
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(RaySrc src, uint32_t *next, uint64_t *counters)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    Counters c = { 0, 0, 0, 0 };
+    trace_engine<RT_BLOCK>(src.S, src, next, stk, c);
     flush_counters(counters, c);
 }
 
-// One lane per pixel; a 256-thread block covers a 16 x 16 pixel tile so that the lanes of a
-// wave (16 x 4 pixels) walk neighbouring rays through the same octree nodes.
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(DevScene S, rt_camera cam, int w, int h,
-                                                             uint32_t *prim_id, double *tout, uint64_t *counters)
+struct PrimarySrc {         // rt_trace_primary: one ray through every pixel centre
+    DevScene S; rt_camera cam; int w, h; uint32_t *prim_id; double *tout;
+    __device__ uint32_t count() const { return (uint32_t)w * (uint32_t)h; }
+    __device__ bool load(uint32_t i, V3 &e, V3 &d, double &a, double &b) const
+    {
+        int x, y;
+        work_pixel(i, w, h, x, y);
+        camera_ray(cam, (float)((0.5 + x * 1.0) / w), (float)((0.5 + y * 1.0) / h), e, d);
+        a = 0.0; b = RT_INFINITE;
+        return true;
+    }
+    __device__ void store(uint32_t i, bool hit, const Hit &hh) const
+    {
+        int x, y;
+        work_pixel(i, w, h, x, y);
+        const uint64_t pix = (uint64_t)y * w + x;
+        prim_id[pix] = hit ? global_prim(S, hh) : RT_MISS;
+        if (tout) tout[pix] = hit ? hh.t : RT_INFINITE;
+    }
+};
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(PrimarySrc src, uint32_t *next, uint64_t *counters)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    const int tiles_x = (w + 15) >> 4;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
     Counters c = { 0, 0, 0, 0 };
-    if (x < w && y < h) {
-        V3 e, d;
-        camera_ray(cam, (float)((0.5 + x * 1.0) / w), (float)((0.5 + y * 1.0) / h), e, d);
-        Hit hh;
-        uint64_t pix = (uint64_t)y * w + x;
-        if (group_hit<RT_BLOCK>(S, e, d, 0.0, RT_INFINITE, hh, stk, c)) {
-            prim_id[pix] = global_prim(S, hh);
-            if (tout) tout[pix] = hh.t;
-        } else {
-            prim_id[pix] = RT_MISS;
-            if (tout) tout[pix] = RT_INFINITE;
-        }
-    }
+    trace_engine<RT_BLOCK>(src.S, src, next, stk, c);
     flush_counters(counters, c);
 }
 
@@ -517,25 +696,6 @@ __device__ __forceinline__ uint64_t wave_append(uint32_t *counter, bool want)
     return (uint64_t)base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// Pixel enumeration: 8 x 8 tiles over the part of the image that whole tiles cover, then the
-// right and top remainders row by row (a bijection on [0, W*H) for any size).
-__device__ __forceinline__ void work_pixel(uint32_t idx, int W, int H, int &x, int &y)
-{
-    const uint32_t Wt = (uint32_t)W & ~7u, Ht = (uint32_t)H & ~7u;
-    const uint32_t tiled = Wt * Ht;
-    if (idx < tiled) {
-        const uint32_t tile = idx >> 6, l = idx & 63u, tx = Wt >> 3;
-        x = (int)((tile % tx) * 8 + (l & 7u));
-        y = (int)((tile / tx) * 8 + (l >> 3));
-        return;
-    }
-    idx -= tiled;
-    const uint32_t rw = (uint32_t)W - Wt;
-    if (idx < rw * (uint32_t)H) { x = (int)(Wt + idx % rw); y = (int)(idx / rw); return; }
-    idx -= rw * (uint32_t)H;
-    x = (int)(idx % Wt); y = (int)(Ht + idx / Wt);
-}
-
 // First rays of work items [first, first+count): item = sample-major (all pixels of sample k,
 // then k+1) so that neighbouring lanes start neighbouring pixels with the same sample index.
 __global__ __launch_bounds__(RT_BLOCK) void k_generate(WaveArgs A, RayStack q, uint64_t slot0, uint64_t first, uint32_t count)
@@ -565,32 +725,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(WaveArgs A, RayStack q, u
 }
 
 // Closest hit for the chunk [base, base+count) of a ray stack.
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, WaveArgs A, RayStack q, uint64_t base, uint32_t count)
-{
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    Counters c = { 0, 0, 0, 0 };
-    if (i < count) {
+struct StackSrc {
+    WaveArgs A; RayStack q; uint64_t base; uint32_t n;
+    __device__ uint32_t count() const { return n; }
+    __device__ bool load(uint32_t i, V3 &e, V3 &d, double &t0, double &t1) const
+    {
         const uint64_t slot = base + i;
         const uint64_t meta = q.f[(uint64_t)RAY_META * q.cap + slot];
         const int jump = (int)((meta >> 56) & 63);
         const bool shadow = (meta >> 63) != 0;
-        uint64_t id = ~0ull;
-        double t = RT_INFINITE;
         // depth cut-off (scene.cpp:196-198) happens before any intersection work
-        if (shadow || jump + 1 <= A.max_jump) {
-            V3 e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
-            V3 d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
-            const bool first = !shadow && jump == A.jumptime && ((meta >> 62) & 1);
-            const double t0 = first ? A.t0 : RT_ZERO;
-            const double t1 = ray_f(q, slot, RAY_T1);
-            Hit h;
-            if (group_hit<RT_BLOCK>(S, e, d, t0, t1, h, stk, c)) { id = ((uint64_t)(uint32_t)h.obj << 32) | h.prim; t = h.t; }
-        }
-        q.hit_t[slot] = t;
-        q.hit_id[slot] = id;
+        if (!shadow && jump + 1 > A.max_jump) return false;
+        e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
+        d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
+        const bool first = !shadow && jump == A.jumptime && ((meta >> 62) & 1);
+        t0 = first ? A.t0 : RT_ZERO;
+        t1 = ray_f(q, slot, RAY_T1);
+        return true;
     }
-    flush_counters(A.counters, c);
+    __device__ void store(uint32_t i, bool hit, const Hit &h) const
+    {
+        const uint64_t slot = base + i;
+        q.hit_t[slot] = hit ? h.t : RT_INFINITE;
+        q.hit_id[slot] = hit ? (((uint64_t)(uint32_t)h.obj << 32) | h.prim) : ~0ull;
+    }
+};
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    Counters c = { 0, 0, 0, 0 };
+    trace_engine<RT_BLOCK>(S, src, next, stk, c);
+    flush_counters(src.A.counters, c);
 }
 
 __device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
@@ -772,19 +937,39 @@ __global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, uin
 }
 
 // ------------------------------------------------------------------ launchers
-hipError_t launch_trace_rays(const DevScene &S, const rt_ray *rays, uint64_t n, double t0, double t1,
+// Persistent grids: no more blocks than stay resident, no more than the rays need.
+static unsigned engine_blocks(uint64_t items, int num_cu, const void *kernel)
+{
+    static thread_local const void *cached_k[3] = { nullptr, nullptr, nullptr };
+    static thread_local int cached_v[3] = { 0, 0, 0 };
+    int per_cu = 0;
+    for (int i = 0; i < 3; i++) if (cached_k[i] == kernel) per_cu = cached_v[i];
+    if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        for (int i = 0; i < 3; i++) if (!cached_k[i]) { cached_k[i] = kernel; cached_v[i] = per_cu; break; }
+    }
+    uint64_t resident = (uint64_t)(num_cu > 0 ? num_cu : 256) * (uint64_t)per_cu;
+    uint64_t need = (items + RT_BLOCK - 1) / RT_BLOCK;
+    return (unsigned)(need < resident ? need : resident);
+}
+hipError_t launch_trace_rays(const DevScene &S, int num_cu, uint32_t *next, const rt_ray *rays, uint64_t n, double t0, double t1,
                              uint32_t *prim_id, double *t, double *normal, uint64_t *counters, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    uint64_t blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
-    hipLaunchKernelGGL(k_trace_rays, dim3((unsigned)blocks), dim3(RT_BLOCK), 0, st, S, rays, n, t0, t1, prim_id, t, normal, counters);
+    RaySrc src = { S, rays, (uint32_t)n, t0, t1, prim_id, t, normal };
+    hipError_t e = hipMemsetAsync(next, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_rays, dim3(engine_blocks(n, num_cu, (const void *)k_trace_rays)), dim3(RT_BLOCK), 0, st, src, next, counters);
     return hipGetLastError();
 }
-hipError_t launch_trace_primary(const DevScene &S, const rt_camera &cam, int w, int h, uint32_t *prim_id, double *t,
-                                uint64_t *counters, hipStream_t st)
+hipError_t launch_trace_primary(const DevScene &S, int num_cu, uint32_t *next, const rt_camera &cam, int w, int h, uint32_t *prim_id,
+                                double *t, uint64_t *counters, hipStream_t st)
 {
-    unsigned blocks = (unsigned)(((w + 15) >> 4) * ((h + 15) >> 4));
-    hipLaunchKernelGGL(k_trace_primary, dim3(blocks), dim3(RT_BLOCK), 0, st, S, cam, w, h, prim_id, t, counters);
+    PrimarySrc src = { S, cam, w, h, prim_id, t };
+    hipError_t e = hipMemsetAsync(next, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_primary, dim3(engine_blocks((uint64_t)w * h, num_cu, (const void *)k_trace_primary)), dim3(RT_BLOCK), 0, st, src, next, counters);
     return hipGetLastError();
 }
 hipError_t launch_generate(const WaveArgs &A, const RayStack &q, uint64_t slot0, uint64_t first, uint32_t count, hipStream_t st)
@@ -793,10 +978,13 @@ hipError_t launch_generate(const WaveArgs &A, const RayStack &q, uint64_t slot0,
     hipLaunchKernelGGL(k_generate, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, A, q, slot0, first, count);
     return hipGetLastError();
 }
-hipError_t launch_trace(const DevScene &S, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count, hipStream_t st)
+hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count, hipStream_t st)
 {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_trace, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, q, base, count);
+    StackSrc src = { A, q, base, count };
+    hipError_t e = hipMemsetAsync(next, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,

@@ -149,15 +149,20 @@ bool build_octree(const double *tris, uint64_t ntris, double pad, int max_size, 
     order.reserve(b.nodes.size());
     order.push_back(0);
     out.nodes.clear();
-    out.obj_index.clear();
+    out.leaf_tris.clear();
     for (size_t fi = 0; fi < order.size(); fi++) {
         const BNode &n = b.nodes[order[fi]];
         FlatNode f;
         for (int k = 0; k < 3; k++) { f.lo[k] = n.box.lo[k]; f.hi[k] = n.box.hi[k]; }
         f.pad = 0;
-        f.obj_begin = (uint32_t)out.obj_index.size();
+        f.obj_begin = (uint32_t)out.leaf_tris.size();
         f.obj_count = (uint32_t)n.objs.size();
-        out.obj_index.insert(out.obj_index.end(), n.objs.begin(), n.objs.end());
+        for (uint32_t o : n.objs) {
+            LeafTri lt;
+            for (int k = 0; k < 3; k++) { lt.v0[k] = out.tri_rec[9ull * o + k]; lt.e1[k] = out.tri_rec[9ull * o + 3 + k]; lt.e2[k] = out.tri_rec[9ull * o + 6 + k]; }
+            lt.id = o; lt.pad = 0;
+            out.leaf_tris.push_back(lt);
+        }
         if (n.full) {
             f.child_base = (uint32_t)order.size();
             for (int i = 0; i < 8; i++) order.push_back(n.child[i]);

@@ -15,17 +15,27 @@ namespace rt {
 struct FlatNode {
     double   lo[3], hi[3];
     uint32_t child_base;
-    uint32_t obj_begin;   // first entry of this node's object list in the index array
+    uint32_t obj_begin;   // first record of this node's triangle run
     uint32_t obj_count;
     uint32_t pad;
 };
 static_assert(sizeof(FlatNode) == 64, "FlatNode must be 64 bytes");
 
-// Triangle record: v0, e1 = v1 - v0, e2 = v2 - v0 (9 doubles, 72 bytes).
+// Triangle as the intersection loop reads it: v0, e1 = v1 - v0, e2 = v2 - v0 and the triangle's
+// index, 80 bytes (five 16-byte loads).  Every node owns a CONTIGUOUS run of these records in
+// its list order (a triangle referenced by several nodes is stored once per reference), so a
+// lane walks its node's triangles with unit stride and no index indirection.
+struct LeafTri {
+    double   v0[3], e1[3], e2[3];
+    uint32_t id;      // triangle index (within the mesh at build time)
+    uint32_t pad;
+};
+static_assert(sizeof(LeafTri) == 80, "LeafTri must be 80 bytes");
+
 struct FlatTree {
-    std::vector<FlatNode> nodes;      // node 0 is the root
-    std::vector<uint32_t> obj_index;  // triangle indices, per node in insertion (list) order
-    std::vector<double>   tri_rec;    // ntris x 9
+    std::vector<FlatNode> nodes;      // node 0 is the root; obj_begin indexes leaf_tris
+    std::vector<LeafTri>  leaf_tris;  // per node, in insertion (list) order
+    std::vector<double>   tri_rec;    // ntris x 9 (v0, e1, e2) by triangle index, for shading
     uint64_t stats[6] = {0, 0, 0, 0, 0, 0}; // nodes, leaves, refs, inner refs, max depth, lost
 };
 
