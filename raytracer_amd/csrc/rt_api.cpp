@@ -190,6 +190,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
             if (o.mesh < 0 || (uint64_t)o.mesh >= d->nmeshes) return fail("rt_scene_create: object " + std::to_string(i) + " has a bad mesh index");
             q.root = mesh_root[o.mesh];
             q.tri_base = mesh_tri_base[o.mesh];
+            const FlatNode &rn = nodes[q.root];
+            q.pad = (rn.child_base == 0) ? rn.obj_count : 0;
             prim += mesh_ntris[o.mesh];
         } else {
             prim += 1;

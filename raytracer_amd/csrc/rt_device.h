@@ -15,7 +15,7 @@ struct DevObject {
     uint32_t root;       // mesh: index of the octree root in DevScene::nodes
     uint32_t tri_base;   // mesh: index of its first triangle record
     uint32_t prim_base;  // global primitive id of the object's first primitive
-    uint32_t pad;
+    uint32_t pad;        // mesh: triangle count if the whole octree is a single leaf, else 0
     double   p[4];
 };
 

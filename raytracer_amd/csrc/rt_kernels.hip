@@ -238,7 +238,7 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 // divisions and the literal comparison forms are used (zero components give the +-inf / NaN
 // cases of hitBox, algorithms.h:208-236).
 enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 5 };
-enum { NODE_MIN = 16, OBJ_MIN = 16 };
+enum { NODE_MIN = 24, OBJ_MIN = 24 };
 
 template <bool FAST> __device__ __forceinline__ double tmin2(double a, double b) { return FAST ? fmin(a, b) : smin(a, b); }
 template <bool FAST> __device__ __forceinline__ double tmax2(double a, double b) { return FAST ? fmax(a, b) : smax(a, b); }
@@ -342,19 +342,25 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
             ct[ci] = r0;
             if (r0 <= r1) hitmask |= 1u << ci;
         }
-        // std::sort by entry distance (octree.cpp:344); equal keys keep child order
-        uint32_t order = 0, cnt = 0;
+        // std::sort by entry distance (octree.cpp:344); equal keys keep child order.  Children that
+        // are not hit get key +inf, so the hit ones take ranks 0..cnt-1; one comparison per pair:
+        // the later child goes first only if its key is strictly smaller.
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (!(hitmask >> i & 1u)) ct[i] = __builtin_huge_val();
+        uint32_t rank[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            uint32_t rank = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (j == i) continue;
-                const bool before = (j < i) ? !(ct[i] < ct[j]) : (ct[j] < ct[i]);
-                rank += (before && (hitmask >> j & 1u)) ? 1u : 0u;
+            for (int j = i + 1; j < 8; j++) {
+                const bool jfirst = ct[j] < ct[i];
+                rank[i] += jfirst ? 1u : 0u;
+                rank[j] += jfirst ? 0u : 1u;
             }
-            if (hitmask >> i & 1u) { order |= (uint32_t)i << (3 * rank); cnt++; }
         }
+        uint32_t order = 0;
+        const uint32_t cnt = (uint32_t)__popc(hitmask);
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (hitmask >> i & 1u) order |= (uint32_t)i << (3 * rank[i]);
         if (cnt) {
             stk[0][T.sp][tid] = child_base;
             stk[1][T.sp][tid] = order | (cnt << 24);
@@ -438,6 +444,19 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     const DevObject &o = S.objects[T.oi];
                     if (o.type == RT_OBJ_MESH) {
                         T.root = o.root; T.cur = o.root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS;   // octree.cpp:312-313
+                        if (o.pad) {
+                            // the whole octree is one leaf (o.pad = its triangle count): open it here,
+                            // saving a node step (octree.cpp:291, then OctreeNode::hit on the root)
+                            const FlatNode *nd = S.nodes + o.root;
+                            double n0, n1;
+                            if (!hit_box(nd->lo, nd->hi, T.e, T.d, T.t0, T.t1, n0, n1)) continue;
+                            c.leaf++;
+                            T.k = nd->obj_begin; T.kend = T.k + o.pad;
+                            T.bt0 = n0; T.bt1 = n1; T.tempt = n1; T.bprim = RT_MISS; T.leaf = true;
+                            nxt = tri_load(S.leaf_tris + T.k);
+                            mode = TM_TRI;
+                            break;
+                        }
                         mode = TM_NODE;
                         break;
                     }

@@ -14,7 +14,7 @@ import numpy as np
 from .desc import CameraC, RAY_DT, RenderParamsC, SceneDescC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")   # RT_HIP_LIB: A/B a differently built library
 
 EXPORTS = (
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
