@@ -1,0 +1,311 @@
+// rt_scene.hpp -- host-side scene API with the reference's class and method names, on top of
+// the C ABI in rt_hip.h.  A driver written against the reference (main.cpp:29-108) ports by
+// changing its includes: build Group / Sphere / Material / Camera / SphereLight objects, hand
+// them to a Scene, call runParallelly(), read pixels with queryColor() or saveToBpm().
+//
+// What differs from the reference, on purpose:
+//   * Scene::runParallelly(threadNum) renders on the GPU (threadNum is accepted and ignored);
+//     there is no CPU rendering path behind this header.
+//   * Mesh is new: a Drawable holding triangles in an Octree (the role HeartShape /
+//     ImplicitSurface play in the reference, Surface.h:131-174).
+//   * the sampler constants that are private members without setters in the reference
+//     (scene.h:52-54) are settable: setSampleNum, setMaxJump, setRusJump, setSeed, setFaceForward.
+//   * only Monte-Carlo materials are accepted (the legacy Phong branch, scene.cpp:305-375, is
+//     not on this path): setRootNode / run report -1 for others.
+// Header-only; link with librt_hip.so.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rt_hip.h"
+
+namespace rt_host {
+
+// types.h:8-93, 97-178
+struct Vec3 {
+    double x_ = 0, y_ = 0, z_ = 0;
+    Vec3() = default;
+    Vec3(double x, double y, double z) : x_(x), y_(y), z_(z) {}
+    Vec3 operator+(const Vec3 &r) const { return Vec3(x_ + r.x_, y_ + r.y_, z_ + r.z_); }
+    Vec3 operator-(const Vec3 &r) const { return Vec3(x_ - r.x_, y_ - r.y_, z_ - r.z_); }
+    Vec3 operator*(double s) const { return Vec3(x_ * s, y_ * s, z_ * s); }
+    Vec3 operator^(const Vec3 &r) const { return Vec3(y_ * r.z_ - r.y_ * z_, z_ * r.x_ - x_ * r.z_, x_ * r.y_ - r.x_ * y_); }
+    double length() const { return std::sqrt(x_ * x_ + y_ * y_ + z_ * z_); }
+    Vec3 normalize() const { return *this * (1 / length()); }
+};
+struct Vec4 {
+    double x_ = 0, y_ = 0, z_ = 0, w_ = 0;
+    Vec4() = default;
+    Vec4(double x, double y, double z, double w) : x_(x), y_(y), z_(z), w_(w) {}
+    Vec4 operator*(double s) const { return Vec4(x_ * s, y_ * s, z_ * s, w_ * s); }
+    Vec4 operator&(const Vec4 &r) const { return Vec4(x_ * r.x_, y_ * r.y_, z_ * r.z_, w_ * r.w_); }
+};
+using Color = Vec4;
+
+// material.h:7-67
+class Material {
+public:
+    enum Type { NULLTYPE = 0x0, NORMAL = 0x1, SPECULAR = 0x2, TRANSPARENT = 0x4, MONTECARLO = 0x8 };
+    Material(Color emission, Color color, Type type)                         // material.cpp:14-17
+    {
+        rec_ = rt_material{};
+        rec_.type = (int)type | MONTECARLO;
+        set3(rec_.emission, emission); set3(rec_.color, color);
+    }
+    Material(Color a, double nr)                                             // material.cpp:19-23
+    {
+        rec_ = rt_material{};
+        rec_.type = TRANSPARENT;
+        set3(rec_.atten, a); rec_.nr = nr;
+    }
+    void setMonteCarlo(Color color = Color(-1, -1, -1, 0), Color emission = Color(-1, -1, -1, 0))   // material.cpp:40-47
+    {
+        rec_.type |= MONTECARLO;
+        if (color.x_ >= 0) set3(rec_.color, color);
+        if (emission.x_ >= 0) set3(rec_.emission, emission);
+    }
+    void setMirrorBlur(double b) { rec_.blur = b; }
+    int getType() const { return rec_.type; }
+    const rt_material &record() const { return rec_; }
+private:
+    static void set3(double *d, const Color &c) { d[0] = c.x_; d[1] = c.y_; d[2] = c.z_; }
+    rt_material rec_;
+};
+
+// Surface.h:47-74
+class Node {
+public:
+    virtual ~Node() = default;
+    int setMaterial(std::shared_ptr<Material> m) { mat_ = std::move(m); return 0; }
+    std::shared_ptr<Material> getMaterial() const { return mat_; }
+    // appends this node (and its children) to a flat description; returns -1 on error
+    virtual int flatten(std::vector<rt_object> &objs, std::vector<rt_material> &mats,
+                        std::vector<std::vector<double>> &meshes) const = 0;
+protected:
+    int material_index(std::vector<rt_material> &mats) const
+    {
+        if (!mat_) return -1;
+        mats.push_back(mat_->record());
+        return (int)mats.size() - 1;
+    }
+    std::shared_ptr<Material> mat_;
+};
+class Drawable : public Node {};
+
+class Sphere : public Drawable {                                             // Surface.h:95-111
+public:
+    Sphere(Vec3 center, double radius) : c_(center), r_(radius) {}
+    int flatten(std::vector<rt_object> &objs, std::vector<rt_material> &mats, std::vector<std::vector<double>> &) const override
+    {
+        rt_object o{}; o.type = RT_OBJ_SPHERE; o.mesh = -1;
+        if ((o.material = material_index(mats)) < 0) return -1;
+        o.p[0] = c_.x_; o.p[1] = c_.y_; o.p[2] = c_.z_; o.p[3] = r_;
+        objs.push_back(o);
+        return 0;
+    }
+private:
+    Vec3 c_; double r_;
+};
+template <int KIND> class Plane_ : public Drawable {                        // Surface.h:176-214
+public:
+    explicit Plane_(double coord) : c_(coord) {}
+    int flatten(std::vector<rt_object> &objs, std::vector<rt_material> &mats, std::vector<std::vector<double>> &) const override
+    {
+        rt_object o{}; o.type = KIND; o.mesh = -1;
+        if ((o.material = material_index(mats)) < 0) return -1;
+        o.p[0] = c_;
+        objs.push_back(o);
+        return 0;
+    }
+private:
+    double c_;
+};
+using Ground = Plane_<RT_OBJ_GROUND>;
+using Wall_z = Plane_<RT_OBJ_WALL_Z>;
+using Wall_x = Plane_<RT_OBJ_WALL_X>;
+
+// New: triangles (v0 v1 v2, 9 doubles each) held in an octree built with the reference policy.
+class Mesh : public Drawable {
+public:
+    explicit Mesh(std::vector<double> tris) : tris_(std::move(tris)) {}
+    void addTriangle(Vec3 a, Vec3 b, Vec3 c)
+    {
+        for (const Vec3 *v : {&a, &b, &c}) { tris_.push_back(v->x_); tris_.push_back(v->y_); tris_.push_back(v->z_); }
+    }
+    int flatten(std::vector<rt_object> &objs, std::vector<rt_material> &mats, std::vector<std::vector<double>> &meshes) const override
+    {
+        if (tris_.size() % 9) return -1;
+        rt_object o{}; o.type = RT_OBJ_MESH;
+        if ((o.material = material_index(mats)) < 0) return -1;
+        meshes.push_back(tris_);
+        o.mesh = (int)meshes.size() - 1;
+        objs.push_back(o);
+        return 0;
+    }
+private:
+    std::vector<double> tris_;
+};
+
+class Group : public Node {                                                  // Surface.h:76-86
+public:
+    void addChild(std::shared_ptr<Node> child) { children_.push_back(std::move(child)); }
+    int flatten(std::vector<rt_object> &objs, std::vector<rt_material> &mats, std::vector<std::vector<double>> &meshes) const override
+    {
+        for (const auto &c : children_) if (c->flatten(objs, mats, meshes)) return -1;
+        return 0;
+    }
+private:
+    std::vector<std::shared_ptr<Node>> children_;
+};
+
+class Camera {                                                               // camera.h:4-28
+public:
+    Camera(Vec3 lookFrom, Vec3 lookAt, Vec3 vup, double vfov, double aspect)
+    {
+        const double f[3] = {lookFrom.x_, lookFrom.y_, lookFrom.z_}, a[3] = {lookAt.x_, lookAt.y_, lookAt.z_}, u[3] = {vup.x_, vup.y_, vup.z_};
+        rt_camera_init(f, a, u, vfov, aspect, &rec_);
+    }
+    const rt_camera &record() const { return rec_; }
+private:
+    rt_camera rec_;
+};
+
+class Light {                                                                // light.h:8-30
+public:
+    virtual ~Light() = default;
+    virtual std::shared_ptr<Drawable> getGeometry() { return nullptr; }
+    const rt_light &record() const { return rec_; }
+protected:
+    rt_light rec_{};
+};
+class SphereLight : public Light {                                           // light.cpp:109-116
+public:
+    SphereLight(Vec3 pos, double radius, Color emission)
+    {
+        rec_.type = RT_LIGHT_SPHERE;
+        rec_.pos[0] = pos.x_; rec_.pos[1] = pos.y_; rec_.pos[2] = pos.z_; rec_.radius = radius;
+        rec_.diffuse[0] = emission.x_; rec_.diffuse[1] = emission.y_; rec_.diffuse[2] = emission.z_;
+        sphere_ = std::make_shared<Sphere>(pos, radius);
+        sphere_->setMaterial(std::make_shared<Material>(emission, Color(), Material::NORMAL));
+    }
+    std::shared_ptr<Drawable> getGeometry() override { return sphere_; }
+private:
+    std::shared_ptr<Sphere> sphere_;
+};
+class FaceLight : public Light {                                             // light.cpp:50-56
+public:
+    FaceLight(Vec3 pos, Vec3 normal, Vec3 up, double width, double height, Color /*ambient*/, Color diffuse, Color /*specular*/)
+    {
+        rec_.type = RT_LIGHT_FACE;
+        const Vec3 right = up ^ normal, n = normal.normalize();
+        rec_.pos[0] = pos.x_; rec_.pos[1] = pos.y_; rec_.pos[2] = pos.z_;
+        rec_.normal[0] = n.x_; rec_.normal[1] = n.y_; rec_.normal[2] = n.z_;
+        rec_.up[0] = up.x_; rec_.up[1] = up.y_; rec_.up[2] = up.z_;
+        rec_.right[0] = right.x_; rec_.right[1] = right.y_; rec_.right[2] = right.z_;
+        rec_.width = width; rec_.height = height;
+        rec_.diffuse[0] = diffuse.x_; rec_.diffuse[1] = diffuse.y_; rec_.diffuse[2] = diffuse.z_;
+    }
+};
+
+class Scene {                                                                // scene.h:8-56
+public:
+    Scene() = default;
+    ~Scene() { if (handle_) rt_scene_destroy(handle_); }
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+
+    int setPixels(int x, int y)                                              // scene.cpp:52-58
+    {
+        if (x <= 0 || y <= 0) return -1;
+        px_ = x; py_ = y; sum_.clear(); run_ = false;
+        return 0;
+    }
+    int getPixels(int *x, int *y) const { if (px_ == -1 || py_ == -1) return -1; *x = px_; *y = py_; return 0; }
+    void setRootNode(std::shared_ptr<Node> node) { node_ = std::move(node); dirty_ = true; }   // scene.cpp:68-73
+    void setCamera(std::shared_ptr<Camera> camera) { camera_ = std::move(camera); }
+    void setClearColor(Color c) { background_ = c; dirty_ = true; }
+    void addLight(std::shared_ptr<Light> light) { lights_.push_back(std::move(light)); dirty_ = true; }   // scene.cpp:86-93
+    // made settable (private constants in the reference, scene.h:52-54; srand value scene.cpp:22)
+    void setSampleNum(int n, int m = -1) { n_ = n; m_ = m < 0 ? n : m; }
+    void setMaxJump(int j) { maxJump_ = j; }
+    void setRusJump(int j) { rusJump_ = j; }
+    void setSeed(uint64_t s) { seed_ = s; }
+    void setFaceForward(bool on) { faceForward_ = on; }
+    void setOctree(int maxSize, int maxDepth) { octMax_ = maxSize; octDepth_ = maxDepth; dirty_ = true; }
+
+    // Scene::run() / runParallelly(threadNum), scene.cpp:95-172: the whole frame, on the GPU.
+    int run() { return runParallelly(0); }
+    int runParallelly(int /*threadNum*/)
+    {
+        if (px_ <= 0 || py_ <= 0 || !camera_) return -1;
+        if (upload()) return -1;
+        rt_render_params p{};
+        p.width = px_; p.height = py_; p.n = n_; p.m = m_; p.sample_begin = 0; p.sample_end = n_ * m_;
+        p.max_jump = maxJump_; p.rus_jump = rusJump_; p.seed = seed_; p.face_forward = faceForward_ ? 1 : 0;
+        sum_.assign((size_t)px_ * py_ * 3, 0.0);
+        if (rt_render_host(handle_, &camera_->record(), &p, sum_.data(), rays_)) return -1;
+        run_ = true;
+        return 0;
+    }
+    // scene.h:72-80; the stored colour is the average, regularized (scene.cpp:112-113)
+    int queryColor(unsigned x, unsigned y, Color &color) const
+    {
+        if (!run_ || x >= (unsigned)px_ || y >= (unsigned)py_) return -1;
+        const double inv = 1.0 / (n_ * m_);
+        const double *s = &sum_[((size_t)y * px_ + x) * 3];
+        auto reg = [](double v) { return v > 1.0 ? 1.0 : (v < 0 ? 0.0 : v); };
+        color = Color(reg(s[0] * inv), reg(s[1] * inv), reg(s[2] * inv), 0);
+        return 0;
+    }
+    int saveToBpm(const char *filename) const                                // scene.cpp:174-192
+    {
+        if (!run_) return -1;
+        std::vector<uint8_t> bgr((size_t)px_ * py_ * 3);
+        if (rt_resolve_bgr8_host(sum_.data(), px_, py_, n_ * m_, bgr.data())) return -1;
+        return rt_save_bmp(bgr.data(), px_, py_, filename) ? -1 : 0;
+    }
+    const char *lastError() const { return rt_last_error(); }
+    uint64_t raysTraced() const { return rays_[0]; }
+
+private:
+    int upload()
+    {
+        if (handle_ && !dirty_) return 0;
+        if (handle_) { rt_scene_destroy(handle_); handle_ = nullptr; }
+        std::vector<rt_object> objs; std::vector<rt_material> mats; std::vector<std::vector<double>> meshes; std::vector<rt_light> lights;
+        if (node_ && node_->flatten(objs, mats, meshes)) return -1;
+        for (const auto &l : lights_) {                                      // light geometry joins the group, scene.cpp:89-91
+            lights.push_back(l->record());
+            if (auto g = l->getGeometry()) if (g->flatten(objs, mats, meshes)) return -1;
+        }
+        std::vector<rt_mesh> mrec(meshes.size());
+        for (size_t i = 0; i < meshes.size(); i++) { mrec[i].tris = meshes[i].data(); mrec[i].ntris = meshes[i].size() / 9; }
+        rt_scene_desc d{};
+        d.objects = objs.data(); d.nobjects = objs.size();
+        d.materials = mats.data(); d.nmaterials = mats.size();
+        d.lights = lights.data(); d.nlights = lights.size();
+        d.meshes = mrec.data(); d.nmeshes = mrec.size();
+        d.background[0] = background_.x_; d.background[1] = background_.y_; d.background[2] = background_.z_;
+        d.tri_box_pad = 1e-7; d.octree_max_size = octMax_; d.octree_overlap_tol = 3; d.octree_max_depth = octDepth_;
+        if (rt_scene_create(&d, &handle_)) return -1;
+        dirty_ = false;
+        return 0;
+    }
+    std::shared_ptr<Node> node_;
+    std::shared_ptr<Camera> camera_;
+    std::vector<std::shared_ptr<Light>> lights_;
+    Color background_;
+    int px_ = -1, py_ = -1;
+    bool run_ = false, dirty_ = true, faceForward_ = false;
+    int n_ = 20, m_ = 20, maxJump_ = 40, rusJump_ = 12;                      // scene.h:52-54
+    int octMax_ = 128, octDepth_ = 12;                                       // octree.h:50
+    uint64_t seed_ = 1243;                                                   // scene.cpp:22
+    rt_scene *handle_ = nullptr;
+    std::vector<double> sum_;
+    uint64_t rays_[4] = {0, 0, 0, 0};
+};
+
+} // namespace rt_host

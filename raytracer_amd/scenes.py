@@ -300,3 +300,31 @@ def three_sphere_scene(light="sphere"):
                      background=(0.05, 0.07, 0.1))
     cam = dict(look_from=(0, 2.5, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=40.0, aspect=4 / 3)
     return desc, cam
+
+
+def kaleidoscope_scene(width=1020, height=630):
+    """The reference driver's own scene (main.cpp:29-72): two huge mirror spheres and three
+    coloured, mirror-finished SphereLights."""
+    PI = 3.1415926
+    R, T, Z = 300.0, 30 * PI / 180., 62.0
+    D = R / math.cos(T)
+    r, g, b = (1.2, 1, 1), (1, 1.1, 1), (1, 1, 1)
+    C, emission = (0.3, 0.7, 0.8), 0.8e-1
+    em = lambda k: tuple(C[i] * emission * k[i] for i in range(3))
+    q = R * 2 * math.sqrt(2. / 3.)
+    base = np.array([50, 28, Z])
+    mats = [material(MAT_SPECULAR, emission=(0, 0, 0), color=(.95, .95, .95)),      # mback
+            material(MAT_SPECULAR, emission=(0, 0, 0), color=(.93, .93, .93)),      # mfront
+            material(MAT_SPECULAR, emission=em(r), color=(1.15, .996, .996)),
+            material(MAT_SPECULAR, emission=em(g), color=(.99, 1.03, .99)),
+            material(MAT_SPECULAR, emission=em(b), color=(.996, .996, .996))]
+    lpos = [base + np.array([math.cos(T), math.sin(T), 0]) * D, base + np.array([-math.cos(T), math.sin(T), 0]) * D,
+            base + np.array([0, -1, 0]) * D]
+    objs = [sphere(base + np.array([0, 0, -1]) * q, R, 0), sphere(base + np.array([0, 0, -q / 3.]), 2 * 2 * q - q / 3., 1)]
+    lights = []
+    for i, (pos, k) in enumerate(zip(lpos, (r, g, b))):
+        lights.append(sphere_light(pos, R, em(k)))
+        objs.append(sphere(pos, R, 2 + i))
+    desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [], background=(0, 0, 0))
+    cam = dict(look_from=(50, 40, -120), look_at=(50, 40, Z), vup=(0, 1, 0), vfov=95.0, aspect=width * 1.0 / height)
+    return desc, cam

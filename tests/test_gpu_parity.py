@@ -311,3 +311,22 @@ def test_profile_counters_are_consistent():
     p = sg.get_profile()
     assert p["trace_launches"] >= 1 and p["trace_ms"] > 0 and p["shade_launches"] == p["trace_launches"]
     assert int(cnt[0]) > 64 * 64 * 4
+
+
+def test_cpp_scene_api_example_matches_oracle(tmp_path):
+    """examples/main_kaleidoscope (the reference driver's scene written against
+    include/rt_scene.hpp, run as its own process) against the oracle's render of that scene."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "main_kaleidoscope")
+    assert os.path.exists(exe), "examples/main_kaleidoscope is not built (__graft_entry__.build())"
+    W, H, n = 102, 63, 3
+    out = str(tmp_path / "k.bmp")
+    subprocess.check_call([exe, str(W), str(H), str(n), out], timeout=120)
+    raw = open(out, "rb").read()
+    got = np.frombuffer(raw[54:], np.uint8).reshape(H, W, 3)
+    desc, cam = scenes.kaleidoscope_scene(W, H)
+    so = orc.OracleScene(desc)
+    img, _ = so.render(orc.camera_init(**cam), render_params(W, H, n, seed=1243))
+    exp = orc.resolve_bgr8(img, n * n)
+    assert (got != exp).mean() < 2e-3           # a last-bit radiance difference may flip a byte
+    assert exp.max() > 20
