@@ -227,6 +227,12 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.tris = (const double *)p_tris;
     s->dev.nobjects = (int32_t)d->nobjects;
     s->dev.nlights = (int32_t)d->nlights;
+    s->dev.regular = 1;
+    for (const FlatNode &f : nodes)
+        for (int k = 0; k < 3; k++) {
+            const double a = std::fabs(f.lo[k]), b = std::fabs(f.hi[k]);
+            if (!((a == 0.0 || (a >= 1e-100 && a <= 1e100)) && (b == 0.0 || (b >= 1e-100 && b <= 1e100)))) s->dev.regular = 0;
+        }
     for (int k = 0; k < 3; k++) s->dev.background[k] = d->background[k];
     s->meshes = infos;
     s->materials = mats;

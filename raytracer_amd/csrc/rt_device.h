@@ -28,6 +28,8 @@ struct DevScene {
     const double      *tris;       // v0, e1, e2 (9 doubles) by global triangle index, for shading normals
     int32_t nobjects;
     int32_t nlights;
+    int32_t regular;               // every node coordinate is 0 or of magnitude 1e-100 .. 1e100
+    int32_t pad;
     double  background[3];
 };
 

@@ -130,13 +130,14 @@ struct Counters { uint32_t rays, inner, leaf, prim; };
 struct TriReg { double v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z; uint32_t id; };
 __device__ __forceinline__ TriReg tri_load(const LeafTri *p)
 {
-    // five 16-byte loads
+    // four 16-byte loads and one 12-byte load (the record's last word is padding and is not
+    // loaded: a register written by a load in flight cannot be reused until the load lands)
     const double2 *q = reinterpret_cast<const double2 *>(p);
     const double2 a = q[0], b = q[1], c = q[2], d = q[3];
-    const double2 e = q[4];
     TriReg r;
-    r.v0x = a.x; r.v0y = a.y; r.v0z = b.x; r.e1x = b.y; r.e1y = c.x; r.e1z = c.y; r.e2x = d.x; r.e2y = d.y; r.e2z = e.x;
-    r.id = (uint32_t)(unsigned long long)__double_as_longlong(e.y);
+    r.v0x = a.x; r.v0y = a.y; r.v0z = b.x; r.e1x = b.y; r.e1y = c.x; r.e1z = c.y; r.e2x = d.x; r.e2y = d.y;
+    r.e2z = p->e2[2];
+    r.id = p->id;
     return r;
 }
 
@@ -256,6 +257,10 @@ __device__ __forceinline__ bool dir_is_regular(V3 d)
     const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
     return ax >= 1e-150 && ax <= 1e150 && ay >= 1e-150 && ay <= 1e150 && az >= 1e-150 && az <= 1e150;
 }
+// coordinates that are zero or of magnitude 1e-100 .. 1e100: differences of two such numbers
+// divided by a regular direction component neither overflow nor reach the subnormal range
+__device__ __forceinline__ bool coord_is_regular(double x) { const double a = fabs(x); return a == 0.0 || (a >= 1e-100 && a <= 1e100); }
+__device__ __forceinline__ bool org_is_regular(V3 e) { return coord_is_regular(e.x) && coord_is_regular(e.y) && coord_is_regular(e.z); }
 
 struct TravState {
     // ray
@@ -268,14 +273,28 @@ struct TravState {
     // octree
     double mint; uint32_t minprim;
     int sp; uint32_t cur, root;
-    // triangle run
+    // triangle run: OctreeNode::hit (octree.cpp:19-38) hands every primitive the window
+    // [bt0, bt1] and keeps a candidate only if t <= tempt; tempt starts at bt1 and only
+    // shrinks, so the window's upper end is tempt itself and the best t so far is tempt too.
     uint32_t k, kend, bprim;
-    double bt0, bt1, tempt, best;
+    double bt0, tempt;
     bool leaf;
 };
 
+// hitBox for a ray with regular direction: same values as hit_box (FAST node steps, above)
+__device__ __forceinline__ bool hit_box_fast(const double *lo, const double *hi, V3 e, V3 d, V3 r, double t0, double t1,
+                                             double &r0o, double &r1o)
+{
+    const double ax = qdiv<true>(lo[0] - e.x, d.x, r.x), ay = qdiv<true>(lo[1] - e.y, d.y, r.y), az = qdiv<true>(lo[2] - e.z, d.z, r.z);
+    const double bx = qdiv<true>(hi[0] - e.x, d.x, r.x), by = qdiv<true>(hi[1] - e.y, d.y, r.y), bz = qdiv<true>(hi[2] - e.z, d.z, r.z);
+    const double r0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t0));
+    const double r1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t1));
+    r0o = r0; r1o = r1;
+    return r0 <= r1;
+}
+
 template <bool FAST, int BLOCK>
-__device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode, TriReg &nxt,
+__device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode,
                                           uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
 {
     const int tid = threadIdx.x;
@@ -309,6 +328,8 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     }
 #ifndef RT_STEP_STATS
     if (child_base) c.inner++; else c.leaf++;
+#else
+    if (RT_STEP_STATS == 2 && !child_base) c.leaf++;
 #endif
     if (child_base) {
         // 8 child slab tests (octree.cpp:337-343) from the {lo, mid, hi} plane distances
@@ -370,10 +391,25 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     if (hb && obj_count) {                                  // OctreeNode::hit, octree.cpp:19-38
         mode = TM_TRI;
         T.k = obj_begin; T.kend = obj_begin + obj_count;
-        T.bt0 = n0; T.bt1 = n1; T.tempt = n1; T.bprim = RT_MISS;
+        T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
         T.leaf = child_base == 0;
-        nxt = tri_load(S.leaf_tris + T.k);
     }
+}
+
+// A lane that has just opened a triangle run loads its first two records; after that every
+// triangle step tests records k and k+1 and refills the two register sets with k+2 and k+3,
+// so a record is always requested one step before it is needed.
+__device__ __forceinline__ void run_open(const DevScene &S, const TravState &T, TriReg &A, TriReg &B)
+{
+    const LeafTri *P = S.leaf_tris + T.k;
+    A = tri_load(P);
+    __builtin_amdgcn_sched_barrier(0);      // keep A's loads older than B's: the first triangle step waits for A only
+    B = tri_load(P + (T.k + 1 < T.kend ? 1 : 0));
+}
+__device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
+{
+    double tt;
+    if (tri_hit(tr, T.e, T.d, T.bt0, T.tempt, tt)) { T.tempt = tt; T.bprim = tr.id; }   // last equal wins, octree.cpp:31
 }
 
 // Src supplies the rays of one launch:
@@ -381,6 +417,9 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
 //   bool load(uint32_t item, V3 &e, V3 &d, double &t0, double &t1) const;  // false: nothing to trace
 //   void store(uint32_t item, bool hit, const Hit &h) const;
 // `next` is a zero-initialised device counter shared by the launch.
+//
+// The step kinds are nested loops (object phase outermost, triangle phase innermost) so that the
+// state a phase does not touch stays put in its registers while that phase repeats.
 template <int BLOCK, class Src>
 __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t *next,
                                     uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
@@ -389,126 +428,148 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
     TravState T = {};
-    TriReg nxt = {};
+    TriReg A = {}, B = {};
     int mode = TM_FETCH;
     for (;;) {
-        const unsigned long long mO = __ballot(mode == TM_FETCH || mode == TM_OBJ);
-        const unsigned long long mN = __ballot(mode == TM_NODE || mode == TM_POP);
-        const unsigned long long mT = __ballot(mode == TM_TRI);
-        if ((mO | mN | mT) == 0ull) break;
-        if (mO != 0ull && ((mN | mT) == 0ull || __popcll(mO) >= OBJ_MIN)) {
-#ifdef RT_STEP_STATS
-            c.rays += 1; if (mode == TM_FETCH || mode == TM_OBJ) c.rays += 1u << 16;
+        // ---------------------------------------------------------------- fetch / object step
+#if RT_STEP_STATS == 1
+        c.rays += 1;
+#elif RT_STEP_STATS == 2
+        if (mode == TM_FETCH || mode == TM_OBJ) c.rays += 1;
 #endif
-            // ------------------------------------------------------------ fetch / object step
-            if (mode == TM_OBJ && T.oi >= 0) {
-                // an octree just finished for object T.oi: Octree::hit's verdict (octree.cpp:371-375)
-                if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
-                T.minprim = RT_MISS;
-            }
-            const unsigned long long need = __ballot(mode == TM_FETCH);
-            if (mode == TM_FETCH) {
-                const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(need));
-                base = __shfl(base, (int)leader, 64);
-                const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (item >= total) {
-                    mode = TM_EXIT;
-                } else {
-                    T.item = item;
-                    T.hobj = -1; T.hprim = 0; T.oi = -1; T.minprim = RT_MISS;
-                    if (src.load(item, T.e, T.d, T.t0, T.t1)) {
-#ifndef RT_STEP_STATS
-                        c.rays++;
-#endif
-                        T.fast = dir_is_regular(T.d);
-                        T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
-                        mode = TM_OBJ;
-                    } else {
-                        Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0;
-                        src.store(item, false, h);          // stays in FETCH
-                    }
-                }
-            }
-            if (mode == TM_OBJ) {
-                // Group::hit, Surface.cpp:160-181: objects in order until the next mesh
-                for (;;) {
-                    T.oi++;
-                    if (T.oi >= S.nobjects) {
-                        Hit h; h.t = T.t1; h.obj = T.hobj; h.prim = T.hprim;
-                        src.store(T.item, T.hobj >= 0, h);
-                        mode = TM_FETCH;
-                        break;
-                    }
-                    const DevObject &o = S.objects[T.oi];
-                    if (o.type == RT_OBJ_MESH) {
-                        T.root = o.root; T.cur = o.root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS;   // octree.cpp:312-313
-                        if (o.pad) {
-                            // the whole octree is one leaf (o.pad = its triangle count): open it here,
-                            // saving a node step (octree.cpp:291, then OctreeNode::hit on the root)
-                            const FlatNode *nd = S.nodes + o.root;
-                            double n0, n1;
-                            if (!hit_box(nd->lo, nd->hi, T.e, T.d, T.t0, T.t1, n0, n1)) continue;
-                            c.leaf++;
-                            T.k = nd->obj_begin; T.kend = T.k + o.pad;
-                            T.bt0 = n0; T.bt1 = n1; T.tempt = n1; T.bprim = RT_MISS; T.leaf = true;
-                            nxt = tri_load(S.leaf_tris + T.k);
-                            mode = TM_TRI;
-                            break;
-                        }
-                        mode = TM_NODE;
-                        break;
-                    }
-                    double t;
-                    const bool hit = (o.type == RT_OBJ_SPHERE) ? sphere_hit(o.p, T.e, T.d, T.t0, T.t1, t)
-                                                               : plane_hit(o.type, o.p[0], T.e, T.d, T.t0, T.t1, t);
-                    if (hit) { T.t1 = t; T.hobj = T.oi; T.hprim = 0; }
-                }
-            }
-            continue;
+        if (mode == TM_OBJ && T.oi >= 0) {
+            // an octree just finished for object T.oi: Octree::hit's verdict (octree.cpp:371-375)
+            if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
+            T.minprim = RT_MISS;
         }
-        if (mN != 0ull && (mT == 0ull || __popcll(mN) >= NODE_MIN)) {
-#ifdef RT_STEP_STATS
-            c.inner += 1; if (mode == TM_NODE || mode == TM_POP) c.leaf += 1;
+        const unsigned long long need = __ballot(mode == TM_FETCH);
+        if (mode == TM_FETCH) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(need));
+            base = __shfl(base, (int)leader, 64);
+            const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            if (item >= total) {
+                mode = TM_EXIT;
+            } else {
+                T.item = item;
+                T.hobj = -1; T.hprim = 0; T.oi = -1; T.minprim = RT_MISS;
+                if (src.load(item, T.e, T.d, T.t0, T.t1)) {
+#ifndef RT_STEP_STATS
+                    c.rays++;
 #endif
-            // ------------------------------------------------------------ node step
-            if (mode == TM_POP) {
-                mode = TM_OBJ;                               // empty stack: this octree is finished
-                while (T.sp > 0) {
-                    const uint32_t w = stk[1][T.sp - 1][tid];
-                    const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
-                    if (pos == cnt) { T.sp--; continue; }
-                    stk[1][T.sp - 1][tid] = w + (1u << 28);
-                    T.cur = stk[0][T.sp - 1][tid] + ((w >> (3 * pos)) & 7u);
+                    T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
+                    T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                    mode = TM_OBJ;
+                } else {
+                    Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0;
+                    src.store(item, false, h);          // stays in FETCH
+                }
+            }
+        }
+        if (mode == TM_OBJ) {
+            // Group::hit, Surface.cpp:160-181: objects in order until the next mesh
+            bool opened = false;
+            for (;;) {
+                T.oi++;
+                if (T.oi >= S.nobjects) {
+                    Hit h; h.t = T.t1; h.obj = T.hobj; h.prim = T.hprim;
+                    src.store(T.item, T.hobj >= 0, h);
+                    mode = TM_FETCH;
+                    break;
+                }
+                const DevObject &o = S.objects[T.oi];
+                if (o.type == RT_OBJ_MESH) {
+                    T.root = o.root; T.cur = o.root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS;   // octree.cpp:312-313
+                    if (o.pad) {
+                        // the whole octree is one leaf (o.pad = its triangle count): open it here,
+                        // saving a node step (octree.cpp:291, then OctreeNode::hit on the root)
+                        const FlatNode *nd = S.nodes + o.root;
+                        double n0, n1;
+                        const bool hb = T.fast ? hit_box_fast(nd->lo, nd->hi, T.e, T.d, T.r, T.t0, T.t1, n0, n1)
+                                               : hit_box(nd->lo, nd->hi, T.e, T.d, T.t0, T.t1, n0, n1);
+                        if (!hb) continue;
+                        c.leaf++;
+                        T.k = nd->obj_begin; T.kend = T.k + o.pad;
+                        T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS; T.leaf = true;
+                        opened = true;
+                        mode = TM_TRI;
+                        break;
+                    }
                     mode = TM_NODE;
                     break;
                 }
+                double t;
+                const bool hit = (o.type == RT_OBJ_SPHERE) ? sphere_hit(o.p, T.e, T.d, T.t0, T.t1, t)
+                                                           : plane_hit(o.type, o.p[0], T.e, T.d, T.t0, T.t1, t);
+                if (hit) { T.t1 = t; T.hobj = T.oi; T.hprim = 0; }
             }
-            const bool in = mode == TM_NODE;
-            if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, nxt, stk, c); }
-            else { if (in) node_step<false, BLOCK>(S, T, mode, nxt, stk, c); }
-            continue;
+            if (opened) run_open(S, T, A, B);
         }
-        // ---------------------------------------------------------------- triangle step
-#ifdef RT_STEP_STATS
-        c.prim += 1u << 16;
+        // ------------------------------------------- node and triangle steps until the next object step
+        bool finished = false;
+        for (;;) {
+            const unsigned long long mO = __ballot(mode == TM_FETCH || mode == TM_OBJ);
+            const unsigned long long mN = __ballot(mode == TM_NODE || mode == TM_POP);
+            const unsigned long long mT = __ballot(mode == TM_TRI);
+            if ((mO | mN | mT) == 0ull) { finished = true; break; }
+            if (mO != 0ull && ((mN | mT) == 0ull || __popcll(mO) >= OBJ_MIN)) break;
+            if (mN != 0ull && (mT == 0ull || __popcll(mN) >= NODE_MIN)) {
+                // -------------------------------------------------------- node step
+#if RT_STEP_STATS == 1
+                c.inner += 1;
+#elif RT_STEP_STATS == 2
+                if (mode == TM_NODE || mode == TM_POP) c.inner += 1;
 #endif
-        if (mode == TM_TRI) {
-            const TriReg tr = nxt;
-            T.k++;
-            if (T.k < T.kend) nxt = tri_load(S.leaf_tris + T.k);
-            c.prim++;
-            double tt;
-            if (tri_hit(tr, T.e, T.d, T.bt0, T.bt1, tt)) {
-                if (tt <= T.tempt) { T.tempt = tt; T.best = tt; T.bprim = tr.id; }   // last equal wins, octree.cpp:31
+                if (mode == TM_POP) {
+                    mode = TM_OBJ;                               // empty stack: this octree is finished
+                    while (T.sp > 0) {
+                        const uint32_t w = stk[1][T.sp - 1][tid];
+                        const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
+                        if (pos == cnt) { T.sp--; continue; }
+                        stk[1][T.sp - 1][tid] = w + (1u << 28);
+                        T.cur = stk[0][T.sp - 1][tid] + ((w >> (3 * pos)) & 7u);
+                        mode = TM_NODE;
+                        break;
+                    }
+                }
+                const bool in = mode == TM_NODE;
+                if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, c); }
+                else { if (in) node_step<false, BLOCK>(S, T, mode, stk, c); }
+                if (in && mode == TM_TRI) run_open(S, T, A, B);
+                continue;
             }
-            if (T.k == T.kend) {
-                bool improved = false;
-                if (T.bprim != RT_MISS && T.best < T.mint) { T.mint = T.best; T.minprim = T.bprim; improved = true; }   // octree.cpp:320-325
-                mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
+            // ------------------------------------------------------------ triangle steps
+            for (;;) {
+#if RT_STEP_STATS == 1
+                c.prim += 1;
+#endif
+                if (mode == TM_TRI) {
+                    const LeafTri *P = S.leaf_tris + T.k;
+                    const uint32_t left = T.kend - T.k;                  // >= 1
+                    // the refills are unconditional (a run that is about to end re-reads its current
+                    // record) so that this stays straight-line code with exact load counting
+                    tri_test(A, T);
+                    A = tri_load(P + (left > 2 ? 2 : 0));
+                    tri_test(B, T);            // left == 1: B is a copy of the run's last record, testing it again changes nothing
+                    B = tri_load(P + (left > 3 ? 3 : 0));
+                    const uint32_t adv = left > 1 ? 2u : 1u;
+                    T.k += adv;
+#if RT_STEP_STATS != 1
+                    c.prim += adv;
+#endif
+                    if (left <= 2) {
+                        bool improved = false;
+                        if (T.bprim != RT_MISS && T.tempt < T.mint) { T.mint = T.tempt; T.minprim = T.bprim; improved = true; }   // octree.cpp:320-325
+                        mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
+                    }
+                }
+                if (__ballot(mode == TM_TRI) == 0ull) break;
+                if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) >= NODE_MIN) break;
+                if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) >= OBJ_MIN) break;
             }
         }
+        if (finished) break;
     }
 }
 
