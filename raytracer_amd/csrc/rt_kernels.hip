@@ -107,11 +107,10 @@ __device__ __forceinline__ double draw(uint64_t key, uint32_t slot) { return u01
 
 // ------------------------------------------------------------------ intersection
 // algorithm::hitBox, algorithms.h:223-236
-__device__ __forceinline__ bool hit_box(const double *lo, const double *hi, V3 e, V3 d, double t0, double t1,
-                                        double &r0o, double &r1o)
+__device__ __forceinline__ bool hit_box(V3 lo, V3 hi, V3 e, V3 d, double t0, double t1, double &r0o, double &r1o)
 {
-    double ax = (lo[0] - e.x) / d.x, ay = (lo[1] - e.y) / d.y, az = (lo[2] - e.z) / d.z;
-    double bx = (hi[0] - e.x) / d.x, by = (hi[1] - e.y) / d.y, bz = (hi[2] - e.z) / d.z;
+    double ax = (lo.x - e.x) / d.x, ay = (lo.y - e.y) / d.y, az = (lo.z - e.z) / d.z;
+    double bx = (hi.x - e.x) / d.x, by = (hi.y - e.y) / d.y, bz = (hi.z - e.z) / d.z;
     double r0 = smin(ax, bx), r1 = smax(ax, bx);
     double m;
     m = smin(ay, by); if (r0 < m) r0 = m;            // std::max_element over {x, y, z, t0}
@@ -167,10 +166,9 @@ __device__ __forceinline__ bool tri_hit(const TriReg &tr, V3 e, V3 d, double t0,
 }
 
 // Sphere::hit, Surface.cpp:73-111 (the tangent branch skips the [t0,t1] window)
-__device__ __forceinline__ bool sphere_hit(const double *p, V3 e, V3 d, double t0, double t1, double &tout)
+__device__ __forceinline__ bool sphere_hit(V3 center, double radius, V3 e, V3 d, double t0, double t1, double &tout)
 {
-    V3 oc = e - mk(p[0], p[1], p[2]);
-    double radius = p[3];
+    V3 oc = e - center;
     double doc = dot(d, oc);
     double dieta = doc * doc - dot(d, d) * (dot(oc, oc) - radius * radius);
     double deno = dot(d, d);
@@ -217,13 +215,13 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 //     FETCH  take the next ray of the launch (persistent lanes: a lane that finishes its ray
 //            takes another one; the lanes of a wave that need rays get consecutive indices
 //            from one atomic, ballot + popcount)
-//     OBJ    advance through the object list; spheres and planes are tested on the spot, a mesh
-//            opens its octree root
+//     OBJ    advance through the object list: spheres, planes and meshes whose octree is a
+//            single leaf are tested on the spot, a larger mesh opens its octree root
 //     NODE / POP   open an octree node / pop the next child from the LDS stack and open it
-//     TRI    walk the triangle run of the opened node, one triangle per step
-// and the wave executes one KIND of step at a time, chosen so that most lanes take part: steps
-// that fetch / open nodes are held back until enough lanes want one (or nobody has triangles
-// left).  Without this a wave would run at the pace of its longest ray and its longest leaf.
+//     TRI    walk the triangle run of the opened node, two triangles per step
+// and the wave executes one KIND of step at a time, the kind most lanes are waiting for (see
+// the weights below).  Without this a wave would run at the pace of its longest ray and its
+// longest leaf.
 //
 // Per open inner node the LDS stack keeps {child_base, visiting order (8 x 3 bits) |
 // count << 24 | next << 28}.  The reference re-checks `minrec.t < next.t` before descending
@@ -239,7 +237,15 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 // divisions and the literal comparison forms are used (zero components give the +-inf / NaN
 // cases of hitBox, algorithms.h:208-236).
 enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 5 };
-enum { NODE_MIN = 24, OBJ_MIN = 24 };
+// Which kind of step a wave runs next: the one with the largest weighted count of waiting
+// lanes.  Weights are in eighths of a triangle-step lane (triangle steps weigh 8); found by
+// timing, a node step is preferred at 2/3 of the triangle lanes, an object phase needs 4/3.
+#ifndef RT_WN
+#define RT_WN 12
+#endif
+#ifndef RT_WO
+#define RT_WO 6
+#endif
 
 template <bool FAST> __device__ __forceinline__ double tmin2(double a, double b) { return FAST ? fmin(a, b) : smin(a, b); }
 template <bool FAST> __device__ __forceinline__ double tmax2(double a, double b) { return FAST ? fmax(a, b) : smax(a, b); }
@@ -282,15 +288,31 @@ struct TravState {
 };
 
 // hitBox for a ray with regular direction: same values as hit_box (FAST node steps, above)
-__device__ __forceinline__ bool hit_box_fast(const double *lo, const double *hi, V3 e, V3 d, V3 r, double t0, double t1,
-                                             double &r0o, double &r1o)
+__device__ __forceinline__ bool hit_box_fast(V3 lo, V3 hi, V3 e, V3 d, V3 r, double t0, double t1, double &r0o, double &r1o)
 {
-    const double ax = qdiv<true>(lo[0] - e.x, d.x, r.x), ay = qdiv<true>(lo[1] - e.y, d.y, r.y), az = qdiv<true>(lo[2] - e.z, d.z, r.z);
-    const double bx = qdiv<true>(hi[0] - e.x, d.x, r.x), by = qdiv<true>(hi[1] - e.y, d.y, r.y), bz = qdiv<true>(hi[2] - e.z, d.z, r.z);
+    const double ax = qdiv<true>(lo.x - e.x, d.x, r.x), ay = qdiv<true>(lo.y - e.y, d.y, r.y), az = qdiv<true>(lo.z - e.z, d.z, r.z);
+    const double bx = qdiv<true>(hi.x - e.x, d.x, r.x), by = qdiv<true>(hi.y - e.y, d.y, r.y), bz = qdiv<true>(hi.z - e.z, d.z, r.z);
     const double r0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t0));
     const double r1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), t1));
     r0o = r0; r1o = r1;
     return r0 <= r1;
+}
+
+// Data that every lane of a wave reads at the same address (the object table, the root node and
+// the triangles of a one-leaf mesh) is read through constant-address-space pointers: the scene
+// is immutable while kernels run, and such reads go through the scalar path.
+#define RT_UNIFORM __attribute__((address_space(4)))
+typedef const DevObject RT_UNIFORM *u_object;
+typedef const FlatNode RT_UNIFORM *u_node;
+typedef const LeafTri RT_UNIFORM *u_leaftri;
+__device__ __forceinline__ TriReg tri_load_uniform(u_leaftri p)
+{
+    TriReg r;
+    r.v0x = p->v0[0]; r.v0y = p->v0[1]; r.v0z = p->v0[2];
+    r.e1x = p->e1[0]; r.e1y = p->e1[1]; r.e1z = p->e1[2];
+    r.e2x = p->e2[0]; r.e2y = p->e2[1]; r.e2z = p->e2[2];
+    r.id = p->id;
+    return r;
 }
 
 template <bool FAST, int BLOCK>
@@ -431,80 +453,104 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     TriReg A = {}, B = {};
     int mode = TM_FETCH;
     for (;;) {
-        // ---------------------------------------------------------------- fetch / object step
+        // ---------------------------------------------------------------- object phase
+        // Group::hit, Surface.cpp:160-181.  Lanes in OBJ mode have just finished the octree of
+        // object T.oi; lanes in FETCH mode need a ray.  A pass hands out rays and then sweeps the
+        // object table once, object by object, all lanes that stand at that object taking part
+        // (a new ray starts at object 0, so within a sweep every lane moves forward until it
+        // reaches an octree or the end of the table).  Two passes: rays that end in the first
+        // one are replaced in the second.
 #if RT_STEP_STATS == 1
         c.rays += 1;
 #elif RT_STEP_STATS == 2
         if (mode == TM_FETCH || mode == TM_OBJ) c.rays += 1;
 #endif
-        if (mode == TM_OBJ && T.oi >= 0) {
-            // an octree just finished for object T.oi: Octree::hit's verdict (octree.cpp:371-375)
-            if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
-            T.minprim = RT_MISS;
-        }
-        const unsigned long long need = __ballot(mode == TM_FETCH);
-        if (mode == TM_FETCH) {
-            const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(need));
-            base = __shfl(base, (int)leader, 64);
-            const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            if (item >= total) {
-                mode = TM_EXIT;
-            } else {
-                T.item = item;
-                T.hobj = -1; T.hprim = 0; T.oi = -1; T.minprim = RT_MISS;
-                if (src.load(item, T.e, T.d, T.t0, T.t1)) {
-#ifndef RT_STEP_STATS
-                    c.rays++;
-#endif
-                    T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
-                    T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
-                    mode = TM_OBJ;
-                } else {
-                    Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0;
-                    src.store(item, false, h);          // stays in FETCH
-                }
-            }
-        }
         if (mode == TM_OBJ) {
-            // Group::hit, Surface.cpp:160-181: objects in order until the next mesh
-            bool opened = false;
-            for (;;) {
-                T.oi++;
-                if (T.oi >= S.nobjects) {
-                    Hit h; h.t = T.t1; h.obj = T.hobj; h.prim = T.hprim;
-                    src.store(T.item, T.hobj >= 0, h);
-                    mode = TM_FETCH;
-                    break;
-                }
-                const DevObject &o = S.objects[T.oi];
-                if (o.type == RT_OBJ_MESH) {
-                    T.root = o.root; T.cur = o.root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS;   // octree.cpp:312-313
-                    if (o.pad) {
-                        // the whole octree is one leaf (o.pad = its triangle count): open it here,
-                        // saving a node step (octree.cpp:291, then OctreeNode::hit on the root)
-                        const FlatNode *nd = S.nodes + o.root;
-                        double n0, n1;
-                        const bool hb = T.fast ? hit_box_fast(nd->lo, nd->hi, T.e, T.d, T.r, T.t0, T.t1, n0, n1)
-                                               : hit_box(nd->lo, nd->hi, T.e, T.d, T.t0, T.t1, n0, n1);
-                        if (!hb) continue;
-                        c.leaf++;
-                        T.k = nd->obj_begin; T.kend = T.k + o.pad;
-                        T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS; T.leaf = true;
-                        opened = true;
-                        mode = TM_TRI;
-                        break;
+            // Octree::hit's verdict (octree.cpp:371-375)
+            if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
+            T.oi++;
+        }
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            const unsigned long long need = __ballot(mode == TM_FETCH);
+            if (mode == TM_FETCH) {
+                const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(need));
+                base = __shfl(base, (int)leader, 64);
+                const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (item >= total) {
+                    mode = TM_EXIT;
+                } else {
+                    T.item = item;
+                    T.hobj = -1; T.hprim = 0; T.oi = 0;
+                    if (src.load(item, T.e, T.d, T.t0, T.t1)) {
+#ifndef RT_STEP_STATS
+                        c.rays++;
+#endif
+                        T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
+                        T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                        mode = TM_OBJ;
+                    } else {
+                        Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0;
+                        src.store(item, false, h);          // stays in FETCH
                     }
-                    mode = TM_NODE;
-                    break;
                 }
-                double t;
-                const bool hit = (o.type == RT_OBJ_SPHERE) ? sphere_hit(o.p, T.e, T.d, T.t0, T.t1, t)
-                                                           : plane_hit(o.type, o.p[0], T.e, T.d, T.t0, T.t1, t);
-                if (hit) { T.t1 = t; T.hobj = T.oi; T.hprim = 0; }
             }
-            if (opened) run_open(S, T, A, B);
+            if (__ballot(mode == TM_OBJ) == 0ull) break;
+            const u_object objects = (u_object)(unsigned long long)S.objects;
+            for (int o = 0; o < S.nobjects; o++) {
+                const bool mine = mode == TM_OBJ && T.oi == o;
+                if (__ballot(mine) == 0ull) continue;
+                const int otype = objects[o].type;
+                if (otype == RT_OBJ_MESH) {
+                    const uint32_t root = objects[o].root, ntri = objects[o].pad;
+                    if (!ntri) {
+                        // an octree with inner nodes: leave the sweep here (octree.cpp:312-313)
+                        if (mine) { T.root = root; T.cur = root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS; mode = TM_NODE; }
+                        continue;
+                    }
+                    // The whole octree is one leaf of ntri triangles: Octree::hit (octree.cpp:285-376)
+                    // reduces to the root's slab test and OctreeNode::hit on it, and all lanes walk
+                    // the same triangle list.
+                    const u_node nd = (u_node)(unsigned long long)(S.nodes + root);
+                    const V3 lo = mk(nd->lo[0], nd->lo[1], nd->lo[2]), hi = mk(nd->hi[0], nd->hi[1], nd->hi[2]);
+                    bool hb = false;
+                    if (mine) {
+                        double n0, n1;
+                        hb = T.fast ? hit_box_fast(lo, hi, T.e, T.d, T.r, T.t0, T.t1, n0, n1) : hit_box(lo, hi, T.e, T.d, T.t0, T.t1, n0, n1);
+                        if (hb) { c.leaf++; c.prim += ntri; T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS; }
+                    }
+                    if (__ballot(hb) != 0ull) {
+                        const u_leaftri P = (u_leaftri)(unsigned long long)(S.leaf_tris + nd->obj_begin);
+#pragma unroll 1
+                        for (uint32_t k = 0; k < ntri; k++) {
+                            const TriReg tr = tri_load_uniform(P + k);
+                            if (hb) tri_test(tr, T);
+                        }
+                        if (hb) {
+                            double mint = T.t1 + 1;                                         // octree.cpp:313
+                            if (T.bprim != RT_MISS && T.tempt < mint) {                     // octree.cpp:320-325
+                                mint = T.tempt;
+                                if (mint <= T.t1) { T.t1 = mint; T.hobj = o; T.hprim = T.bprim; }   // octree.cpp:371-375
+                            }
+                        }
+                    }
+                } else if (mine) {
+                    const double p0 = objects[o].p[0], p1 = objects[o].p[1], p2 = objects[o].p[2], p3 = objects[o].p[3];
+                    double t;
+                    const bool hit = (otype == RT_OBJ_SPHERE) ? sphere_hit(mk(p0, p1, p2), p3, T.e, T.d, T.t0, T.t1, t)
+                                                              : plane_hit(otype, p0, T.e, T.d, T.t0, T.t1, t);
+                    if (hit) { T.t1 = t; T.hobj = o; T.hprim = 0; }
+                }
+                if (mine) T.oi = o + 1;
+            }
+            if (mode == TM_OBJ) {
+                // past the last object: the ray is done
+                Hit h; h.t = T.t1; h.obj = T.hobj; h.prim = T.hprim;
+                src.store(T.item, T.hobj >= 0, h);
+                mode = TM_FETCH;
+            }
         }
         // ------------------------------------------- node and triangle steps until the next object step
         bool finished = false;
@@ -513,8 +559,9 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
             const unsigned long long mN = __ballot(mode == TM_NODE || mode == TM_POP);
             const unsigned long long mT = __ballot(mode == TM_TRI);
             if ((mO | mN | mT) == 0ull) { finished = true; break; }
-            if (mO != 0ull && ((mN | mT) == 0ull || __popcll(mO) >= OBJ_MIN)) break;
-            if (mN != 0ull && (mT == 0ull || __popcll(mN) >= NODE_MIN)) {
+            const int nO = __popcll(mO) * RT_WO, nN = __popcll(mN) * RT_WN, nT = __popcll(mT) * 8;
+            if (nO != 0 && nO >= nN && nO >= nT) break;
+            if (nN != 0 && nN >= nT) {
                 // -------------------------------------------------------- node step
 #if RT_STEP_STATS == 1
                 c.inner += 1;
@@ -564,9 +611,10 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
                     }
                 }
-                if (__ballot(mode == TM_TRI) == 0ull) break;
-                if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) >= NODE_MIN) break;
-                if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) >= OBJ_MIN) break;
+                const int nT = __popcll(__ballot(mode == TM_TRI)) * 8;
+                if (nT == 0) break;
+                if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) * RT_WN >= nT) break;
+                if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) * RT_WO >= nT) break;
             }
         }
         if (finished) break;
