@@ -953,11 +953,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         wn = norm(w);
         sum = sum + had(W, emission * Ed);
     }
-    {
-        const uint64_t s = wave_append(dst_count, lobeN);
-        if (lobeN) ray_store(dst, dst_base + s, p, dn, RT_INFINITE, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0, RAY_RADIANCE));
-    }
-    for (int li = 0; li < S.nlights; li++) {                                 // next-event estimation, scene.cpp:223-246
+    // next-event estimation, scene.cpp:223-246; the shadow ray of light 0 is appended together
+    // with the lobe rays below, further lights append theirs one by one
+    bool want0 = false;
+    V3 ldir0 = mk(0, 0, 0), contrib0 = mk(0, 0, 0);
+    double dist0 = 0;
+    for (int li = 0; li < S.nlights; li++) {
         bool want = false;
         V3 ldir = mk(0, 0, 0), contrib = mk(0, 0, 0);
         double dist = 0;
@@ -980,6 +981,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
                 }
             }
         }
+        if (li == 0) { want0 = want; ldir0 = ldir; contrib0 = contrib; dist0 = dist; continue; }
         const uint64_t s = wave_append(dst_count, want);
         if (want) ray_store(dst, dst_base + s, p, ldir, dist - RT_ZERO, contrib, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
     }
@@ -1006,10 +1008,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         }
         sum = sum + had(W, emission * Ed);
     }
-    {
-        const uint64_t s = wave_append(dst_count, lobeS);
-        if (lobeS) ray_store(dst, dst_base + s, p, md, RT_INFINITE, had(W, mcolor), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
-    }
 
     // ---- dielectric lobe, scene.cpp:267-303
     const bool lobeT = alive && (mtype & RT_MAT_TRANSPARENT);
@@ -1035,13 +1033,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             R = R0 + (1 - R0) * pow(1 - cosv, 5.0);
         }
     }
+    const bool wantT = lobeT && !tir;
+
+    // ---- append the follow-up rays: one slot reservation per block for the five kinds (diffuse
+    // bounce, shadow ray of light 0, mirror, reflected, refracted); a block's rays of one kind
+    // end up next to each other
     {
+        __shared__ uint32_t wave_total[RT_BLOCK / 64], block_base;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned long long m0 = __ballot(lobeN), m1 = __ballot(want0), m2 = __ballot(lobeS), m3 = __ballot(lobeT), m4 = __ballot(wantT);
+        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3), c4 = (uint32_t)__popcll(m4);
+        if (lane == 0) wave_total[wv] = c0 + c1 + c2 + c3 + c4;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int i = 0; i < RT_BLOCK / 64; i++) tot += wave_total[i];
+            block_base = tot ? atomicAdd(dst_count, tot) : 0u;
+        }
+        __syncthreads();
+        uint64_t s = dst_base + block_base;
+        for (uint32_t i = 0; i < wv; i++) s += wave_total[i];
+        if (lobeN) ray_store(dst, s + (uint32_t)__popcll(m0 & lt), p, dn, RT_INFINITE, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0, RAY_RADIANCE));
+        s += c0;
+        if (want0) ray_store(dst, s + (uint32_t)__popcll(m1 & lt), p, ldir0, dist0 - RT_ZERO, contrib0, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
+        s += c1;
+        if (lobeS) ray_store(dst, s + (uint32_t)__popcll(m2 & lt), p, md, RT_INFINITE, had(W, mcolor), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        s += c2;
         // reflected ray: weight k (total internal reflection) or k*R
-        const uint64_t s = wave_append(dst_count, lobeT);
-        if (lobeT) ray_store(dst, dst_base + s, p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
-        const bool wantT = lobeT && !tir;
-        const uint64_t s2 = wave_append(dst_count, wantT);
-        if (wantT) ray_store(dst, dst_base + s2, p, rfr, RT_INFINITE, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        if (lobeT) ray_store(dst, s + (uint32_t)__popcll(m3 & lt), p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        s += c3;
+        if (wantT) ray_store(dst, s + (uint32_t)__popcll(m4 & lt), p, rfr, RT_INFINITE, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
     }
 
     if (live) add_radiance(A.out, pix, sum);
