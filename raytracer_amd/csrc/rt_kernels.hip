@@ -246,7 +246,6 @@ enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 
 #ifndef RT_WO
 #define RT_WO 6
 #endif
-
 template <bool FAST> __device__ __forceinline__ double tmin2(double a, double b) { return FAST ? fmin(a, b) : smin(a, b); }
 template <bool FAST> __device__ __forceinline__ double tmax2(double a, double b) { return FAST ? fmax(a, b) : smax(a, b); }
 template <bool FAST> __device__ __forceinline__ double qdiv(double a, double d, double r)
@@ -362,8 +361,9 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         const double mxL[3] = { tmax2<FAST>(al0, am0), tmax2<FAST>(al1, am1), tmax2<FAST>(al2, am2) };
         const double mnH[3] = { tmin2<FAST>(am0, ah0), tmin2<FAST>(am1, ah1), tmin2<FAST>(am2, ah2) };
         const double mxH[3] = { tmax2<FAST>(am0, ah0), tmax2<FAST>(am1, ah1), tmax2<FAST>(am2, ah2) };
+        // entry distance per child, +inf for children the ray misses
         double ct[8];
-        uint32_t hitmask = 0;
+        uint32_t cnt = 0;
 #pragma unroll
         for (int ci = 0; ci < 8; ci++) {
             // corner order of getChildBound: x-half, y-half, z-half of child ci
@@ -382,28 +382,27 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
                 q = hz ? mxH[2] : mxL[2]; if (q < r1) r1 = q;
                 if (t1 < r1) r1 = t1;
             }
-            ct[ci] = r0;
-            if (r0 <= r1) hitmask |= 1u << ci;
+            const bool h = r0 <= r1;
+            ct[ci] = h ? r0 : __builtin_huge_val();
+            cnt += h ? 1u : 0u;
         }
-        // std::sort by entry distance (octree.cpp:344); equal keys keep child order.  Children that
-        // are not hit get key +inf, so the hit ones take ranks 0..cnt-1; one comparison per pair:
-        // the later child goes first only if its key is strictly smaller.
-#pragma unroll
-        for (int i = 0; i < 8; i++) if (!(hitmask >> i & 1u)) ct[i] = __builtin_huge_val();
-        uint32_t rank[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        // std::sort by entry distance (octree.cpp:344); equal keys keep child order.  rank[i] is
+        // child i's place in that order: i, plus later children that go first (strictly smaller
+        // key), minus earlier children it overtakes.  The hit children take ranks 0..cnt-1.
+        // Child 0 contributes nothing to the packed order word, so its rank is not formed.
+        uint32_t rank[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
 #pragma unroll
         for (int i = 0; i < 8; i++) {
 #pragma unroll
             for (int j = i + 1; j < 8; j++) {
-                const bool jfirst = ct[j] < ct[i];
-                rank[i] += jfirst ? 1u : 0u;
-                rank[j] += jfirst ? 0u : 1u;
+                const uint32_t jfirst = ct[j] < ct[i] ? 1u : 0u;
+                if (i) rank[i] += jfirst;
+                rank[j] -= jfirst;
             }
         }
         uint32_t order = 0;
-        const uint32_t cnt = (uint32_t)__popc(hitmask);
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (hitmask >> i & 1u) order |= (uint32_t)i << (3 * rank[i]);
+        for (int i = 1; i < 8; i++) order |= (uint32_t)i << (3 * rank[i]);
         if (cnt) {
             stk[0][T.sp][tid] = child_base;
             stk[1][T.sp][tid] = order | (cnt << 24);
@@ -455,11 +454,10 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     for (;;) {
         // ---------------------------------------------------------------- object phase
         // Group::hit, Surface.cpp:160-181.  Lanes in OBJ mode have just finished the octree of
-        // object T.oi; lanes in FETCH mode need a ray.  A pass hands out rays and then sweeps the
+        // object T.oi; lanes in FETCH mode need a ray.  The phase hands out rays and then sweeps the
         // object table once, object by object, all lanes that stand at that object taking part
         // (a new ray starts at object 0, so within a sweep every lane moves forward until it
-        // reaches an octree or the end of the table).  Two passes: rays that end in the first
-        // one are replaced in the second.
+        // reaches an octree or the end of the table).
 #if RT_STEP_STATS == 1
         c.rays += 1;
 #elif RT_STEP_STATS == 2
@@ -470,8 +468,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
             if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
             T.oi++;
         }
-#pragma unroll 1
-        for (int pass = 0; pass < 2; pass++) {
+        {
             const unsigned long long need = __ballot(mode == TM_FETCH);
             if (mode == TM_FETCH) {
                 const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
@@ -497,7 +494,6 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     }
                 }
             }
-            if (__ballot(mode == TM_OBJ) == 0ull) break;
             const u_object objects = (u_object)(unsigned long long)S.objects;
             for (int o = 0; o < S.nobjects; o++) {
                 const bool mine = mode == TM_OBJ && T.oi == o;
