@@ -50,10 +50,10 @@ struct rt_scene {
     int nlights = 0;
     int max_push = 1;             // most follow-up rays one shaded hit can append
     // path-tracing workspace (grown on demand, reused by later calls)
-    RayStack stack[2] = {};
-    void *stack_mem[2] = {nullptr, nullptr};
-    uint32_t *d_ctrl = nullptr;   // [0] rays appended by the running shade kernel
-    uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0]
+    RayStack stack[2][2] = {};    // [class][side]
+    void *stack_mem[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint32_t *d_ctrl = nullptr;   // [0],[1] rays appended per class by the running kernel; [2] k_trace's ray counter; [3] the closest-hit entry points' ray counter
+    uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0..1]
     int failed = 0;               // a render ran out of ray-stack space
     // optional stage timing
     int profiling = 0;
@@ -114,7 +114,7 @@ int rt_scene_destroy(rt_scene *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    for (int k = 0; k < 2; k++) if (s->stack_mem[k]) (void)hipFree(s->stack_mem[k]);
+    for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) if (s->stack_mem[c][k]) (void)hipFree(s->stack_mem[c][k]);
     if (s->d_ctrl) (void)hipFree(s->d_ctrl);
     if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
     for (int k = 0; k < 3; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
@@ -191,7 +191,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
             q.root = mesh_root[o.mesh];
             q.tri_base = mesh_tri_base[o.mesh];
             const FlatNode &rn = nodes[q.root];
-            q.pad = (rn.child_base == 0) ? rn.obj_count : 0;
+            q.ntri = (rn.child_base == 0) ? rn.obj_count : 0;
+            q.leaf_begin = rn.obj_begin;
+            for (int k = 0; k < 3; k++) { q.lo[k] = rn.lo[k]; q.hi[k] = rn.hi[k]; }
             prim += mesh_ntris[o.mesh];
         } else {
             prim += 1;
@@ -228,6 +230,19 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.nobjects = (int32_t)d->nobjects;
     s->dev.nlights = (int32_t)d->nlights;
     s->dev.regular = 1;
+    s->dev.nbig = 0;
+    for (const DevObject &q : objs)
+        if (q.type == RT_OBJ_MESH && q.ntri == 0) {
+            // an octree with inner nodes; past RT_MAX_BIG of them the last box grows to hold the rest
+            const FlatNode &rn = nodes[q.root];
+            const bool fresh = s->dev.nbig < RT_MAX_BIG;
+            const int b = fresh ? s->dev.nbig++ : RT_MAX_BIG - 1;
+            for (int k = 0; k < 3; k++) {
+                const float lo = std::nextafter((float)rn.lo[k], -INFINITY), hi = std::nextafter((float)rn.hi[k], INFINITY);
+                s->dev.big_lo[b][k] = fresh ? lo : std::fmin(s->dev.big_lo[b][k], lo);
+                s->dev.big_hi[b][k] = fresh ? hi : std::fmax(s->dev.big_hi[b][k], hi);
+            }
+        }
     for (const FlatNode &f : nodes)
         for (int k = 0; k < 3; k++) {
             const double a = std::fabs(f.lo[k]), b = std::fabs(f.hi[k]);
@@ -260,7 +275,7 @@ int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double
     if (n && (!rays || !prim_id)) return fail("rt_trace_rays: null buffer");
     if (n >= 0xFFFFFFFFull) return fail("rt_trace_rays: batch too large");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 2, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 3, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -270,17 +285,19 @@ int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *
     if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail("rt_trace_primary: bad image size");
     if (!prim_id) return fail("rt_trace_primary: null buffer");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 2, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 3, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
     return 0;
 }
 
 // ---------------------------------------------------------------- wavefront driver
-// Two ray stacks alternate as source and destination.  Each round pops a chunk of at most
-// `target` rays from the top of the source (the most recently appended, i.e. deepest, rays),
-// traces and shades it, and appends the follow-up rays to the other stack, which becomes the
-// next source.  New camera rays are added while the source holds fewer than `target` rays,
-// which keeps the trace kernel's grid full until every sample has been issued ("path
-// regeneration").  One 4-byte read-back per round tells the host how many rays were appended.
+// Pending rays live on stacks, two per ray class (see RayDest).  Each round pops a chunk of at
+// most `target` rays from the top of one stack (the most recently appended, i.e. deepest, rays
+// of the class that has more of them), traces and shades it, and appends the follow-up rays:
+// those of the chunk's own class to that class's other stack, which becomes its source, those
+// of the other class on top of that class's source.  New camera rays are added while the
+// fuller class holds fewer than `target` rays, which keeps the trace kernel's grid full until
+// every sample has been issued ("path regeneration").  One 8-byte read-back after each
+// appending step tells the host how many rays each class received.
 static uint64_t env_u64(const char *name, uint64_t dflt)
 {
     const char *v = std::getenv(name);
@@ -292,18 +309,19 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
 
 static int ensure_stacks(rt_scene *s, uint64_t cap, hipStream_t st)
 {
-    if (s->stack[0].cap >= cap) return 0;
+    if (s->stack[0][0].cap >= cap) return 0;
     HIP_TRY(hipStreamSynchronize(st));
-    for (int k = 0; k < 2; k++) {
-        if (s->stack_mem[k]) { HIP_TRY(hipFree(s->stack_mem[k])); s->stack_mem[k] = nullptr; s->stack[k].cap = 0; }
-        const size_t words = (size_t)cap * (RAY_FIELDS + 2);
-        HIP_TRY(hipMalloc(&s->stack_mem[k], words * sizeof(uint64_t)));
-        uint64_t *base = (uint64_t *)s->stack_mem[k];
-        s->stack[k].f = base;
-        s->stack[k].hit_t = (double *)(base + (size_t)cap * RAY_FIELDS);
-        s->stack[k].hit_id = base + (size_t)cap * (RAY_FIELDS + 1);
-        s->stack[k].cap = cap;
-    }
+    for (int c = 0; c < 2; c++)
+        for (int k = 0; k < 2; k++) {
+            if (s->stack_mem[c][k]) { HIP_TRY(hipFree(s->stack_mem[c][k])); s->stack_mem[c][k] = nullptr; s->stack[c][k].cap = 0; }
+            const size_t words = (size_t)cap * (RAY_FIELDS + 2);
+            HIP_TRY(hipMalloc(&s->stack_mem[c][k], words * sizeof(uint64_t)));
+            uint64_t *base = (uint64_t *)s->stack_mem[c][k];
+            s->stack[c][k].f = base;
+            s->stack[c][k].hit_t = (double *)(base + (size_t)cap * RAY_FIELDS);
+            s->stack[c][k].hit_id = base + (size_t)cap * (RAY_FIELDS + 1);
+            s->stack[c][k].cap = cap;
+        }
     return 0;
 }
 
@@ -319,35 +337,60 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
     if (cap >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
     if (int rc = ensure_stacks(s, cap, st)) return rc;
 
-    uint64_t count[2] = {0, 0};
+    uint64_t count[2][2] = {{0, 0}, {0, 0}};      // [class][side]
+    int cur[2] = {0, 0};                          // side that is the class's source
     uint64_t issued = 0;
-    int src = 0;
-    for (;;) {
-        if (count[src] == 0 && count[src ^ 1] != 0) src ^= 1;
-        // top up with first rays
-        if (issued < total_items && count[src] < target) {
-            uint64_t m = target - count[src];
-            if (m > total_items - issued) m = total_items - issued;
-            HIP_TRY(launch_generate(A, s->stack[src], count[src], issued, (uint32_t)m, st));
-            s->prof[4] += 1;
-            count[src] += m;
-            issued += m;
-        }
-        if (count[src] == 0) break;
-        const int dst = src ^ 1;
-        uint64_t c = count[src] < target ? count[src] : target;
-        const uint64_t room = (cap - count[dst]) / max_push;
-        if (c > room) c = room;
-        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
-        const uint64_t base = count[src] - c;
-        HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 4, st));
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
-        HIP_TRY(launch_trace(s->dev, s->num_cu, s->d_ctrl + 1, A, s->stack[src], base, (uint32_t)c, st));
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
-        HIP_TRY(launch_shade(s->dev, A, s->stack[src], base, (uint32_t)c, s->stack[dst], count[dst], s->d_ctrl, st));
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
-        HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->d_ctrl, 4, hipMemcpyDeviceToHost, st));
+    // appends `what` (a kernel launch that fills dst) and adds the per-class counts to `to`
+    auto read_counts = [&](uint64_t &n0, uint64_t &n1) -> int {
+        HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->d_ctrl, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        n0 = s->h_ctrl[0]; n1 = s->h_ctrl[1];
+        return 0;
+    };
+    for (;;) {
+        for (int c = 0; c < 2; c++) if (count[c][cur[c]] == 0 && count[c][cur[c] ^ 1] != 0) cur[c] ^= 1;
+        uint64_t have = count[0][cur[0]] > count[1][cur[1]] ? count[0][cur[0]] : count[1][cur[1]];
+        // top up with first rays
+        if (issued < total_items && have < target) {
+            uint64_t m = target - have;
+            if (m > total_items - issued) m = total_items - issued;
+            for (int c = 0; c < 2; c++) if (m > cap - count[c][cur[c]]) m = cap - count[c][cur[c]];
+            if (m) {
+                RayDest D;
+                for (int c = 0; c < 2; c++) { D.q[c] = s->stack[c][cur[c]]; D.base[c] = count[c][cur[c]]; }
+                D.count = s->d_ctrl;
+                HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 8, st));
+                HIP_TRY(launch_generate(s->dev, A, D, issued, (uint32_t)m, st));
+                uint64_t n0, n1;
+                if (int rc = read_counts(n0, n1)) return rc;
+                count[0][cur[0]] += n0; count[1][cur[1]] += n1;
+                s->prof[4] += 1;
+                issued += m;
+            }
+        }
+        const int X = count[0][cur[0]] > count[1][cur[1]] ? 0 : 1, Y = X ^ 1;
+        if (count[X][cur[X]] == 0) {
+            if (issued < total_items) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+            break;
+        }
+        uint64_t c = count[X][cur[X]] < target ? count[X][cur[X]] : target;
+        const uint64_t roomX = (cap - count[X][cur[X] ^ 1]) / max_push, roomY = (cap - count[Y][cur[Y]]) / max_push;
+        if (c > roomX) c = roomX;
+        if (c > roomY) c = roomY;
+        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+        const uint64_t base = count[X][cur[X]] - c;
+        RayDest D;
+        D.q[X] = s->stack[X][cur[X] ^ 1]; D.base[X] = count[X][cur[X] ^ 1];
+        D.q[Y] = s->stack[Y][cur[Y]];     D.base[Y] = count[Y][cur[Y]];
+        D.count = s->d_ctrl;
+        HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 8, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+        HIP_TRY(launch_trace(s->dev, s->num_cu, s->d_ctrl + 2, A, s->stack[X][cur[X]], base, (uint32_t)c, X, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
+        HIP_TRY(launch_shade(s->dev, A, s->stack[X][cur[X]], base, (uint32_t)c, D, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
+        uint64_t n[2];
+        if (int rc = read_counts(n[0], n[1])) return rc;
         if (s->profiling) {
             float a = 0, b = 0;
             HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
@@ -355,9 +398,10 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
             s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
         }
         s->prof[5] += 1;
-        count[src] -= c;
-        count[dst] += s->h_ctrl[0];
-        if (s->h_ctrl[0]) src = dst;
+        count[X][cur[X]] -= c;
+        count[X][cur[X] ^ 1] += n[X];
+        count[Y][cur[Y]] += n[Y];
+        if (n[X]) cur[X] ^= 1;
     }
     return 0;
 }

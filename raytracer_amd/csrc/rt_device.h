@@ -7,17 +7,24 @@
 
 namespace rt {
 
-// One Group child as the kernels see it (objects are walked in Group order by every lane, so
-// this table is read through the scalar path).
+// One Group child as the kernels see it.  The object phase of the closest-hit engine reads
+// this table at wave-uniform addresses (scalar loads); a record carries everything that phase
+// needs for the object so that no dependent look-up follows: the first 16 bytes say what to do,
+// the rest is fetched only by the branch that uses it.
 struct DevObject {
     int32_t  type;       // RT_OBJ_*
-    int32_t  material;
+    uint32_t ntri;       // mesh whose whole octree is a single leaf: its triangle count, else 0
     uint32_t root;       // mesh: index of the octree root in DevScene::nodes
+    uint32_t leaf_begin; // mesh with ntri != 0: index of the leaf's first record in DevScene::leaf_tris
+    int32_t  material;
     uint32_t tri_base;   // mesh: index of its first triangle record
     uint32_t prim_base;  // global primitive id of the object's first primitive
-    uint32_t pad;        // mesh: triangle count if the whole octree is a single leaf, else 0
-    double   p[4];
+    uint32_t pad0;
+    double   p[4];       // sphere: centre, radius; plane: coordinate
+    double   lo[3], hi[3];   // mesh with ntri != 0: the root's box
+    double   pad1[2];
 };
+static_assert(sizeof(DevObject) == 128, "DevObject must be 128 bytes");
 
 struct DevScene {
     const DevObject   *objects;
@@ -29,10 +36,12 @@ struct DevScene {
     int32_t nobjects;
     int32_t nlights;
     int32_t regular;               // every node coordinate is 0 or of magnitude 1e-100 .. 1e100
-    int32_t pad;
+    int32_t nbig;                  // octrees with inner nodes whose root boxes are listed below (at most RT_MAX_BIG)
     double  background[3];
+    float   big_lo[4][3], big_hi[4][3];
 };
 
+enum { RT_MAX_BIG = 4 };
 enum { RT_STACK_LEVELS = 16 };     // octree depth <= 15 -> at most 16 open nodes
 enum { RT_BLOCK = 256 };
 
@@ -41,7 +50,7 @@ enum { RT_BLOCK = 256 };
 //   k_generate  appends camera rays for the next (pixel, sample) work items,
 //   k_trace     finds the closest hit of every ray of the chunk on top of the source stack,
 //   k_shade     consumes the hits: adds radiance to the pixel sums and appends the follow-up
-//               rays (bounce rays and shadow rays) to the destination stack.
+//               rays (bounce rays and shadow rays) to the destination stacks.
 // A ray record is 12 eight-byte words stored field-major (one array per field), so that the
 // lanes of a wave read and write consecutive addresses.
 enum { RAY_EX = 0, RAY_EY, RAY_EZ, RAY_DX, RAY_DY, RAY_DZ, RAY_T1, RAY_WX, RAY_WY, RAY_WZ, RAY_KEY, RAY_META, RAY_FIELDS };
@@ -55,6 +64,16 @@ struct RayStack {
     double   *hit_t;    // cap
     uint64_t *hit_id;   // cap: obj << 32 | prim, or ~0 for a miss
     uint64_t  cap;
+};
+
+// Follow-up rays are appended to one of two stacks by class: class 1 rays reach the root box of
+// an octree with inner nodes (they will run node and triangle steps), class 0 rays do not (they
+// finish within object phases).  Tracing the classes in separate launches keeps the lanes of a
+// wave in step; the class never changes what a ray returns.
+struct RayDest {
+    RayStack  q[2];
+    uint64_t  base[2];      // first free slot of each stack
+    uint32_t *count;        // count[0], count[1]: rays appended by the running kernel (zeroed by the host)
 };
 
 struct WaveArgs {

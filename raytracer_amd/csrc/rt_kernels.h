@@ -13,10 +13,12 @@ hipError_t launch_trace_rays(const DevScene &S, int num_cu, uint32_t *next, cons
 hipError_t launch_trace_primary(const DevScene &S, int num_cu, uint32_t *next, const rt_camera &cam, int w, int h, uint32_t *prim_id,
                                 double *t, uint64_t *counters, hipStream_t st);
 // wavefront path-tracing stages (see rt_device.h)
-hipError_t launch_generate(const WaveArgs &A, const RayStack &q, uint64_t slot0, uint64_t first, uint32_t count, hipStream_t st);
-hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count, hipStream_t st);
+hipError_t launch_generate(const DevScene &S, const WaveArgs &A, const RayDest &dst, uint64_t first, uint32_t count, hipStream_t st);
+// ray_class: the class of the chunk's rays (see RayDest)
+hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
+                        int ray_class, hipStream_t st);
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
-                        const RayStack &dst, uint64_t dst_base, uint32_t *dst_count, hipStream_t st);
+                        const RayDest &dst, hipStream_t st);
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st);
 
 } // namespace rt

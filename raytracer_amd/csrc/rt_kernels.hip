@@ -302,7 +302,6 @@ __device__ __forceinline__ bool hit_box_fast(V3 lo, V3 hi, V3 e, V3 d, V3 r, dou
 // is immutable while kernels run, and such reads go through the scalar path.
 #define RT_UNIFORM __attribute__((address_space(4)))
 typedef const DevObject RT_UNIFORM *u_object;
-typedef const FlatNode RT_UNIFORM *u_node;
 typedef const LeafTri RT_UNIFORM *u_leaftri;
 __device__ __forceinline__ TriReg tri_load_uniform(u_leaftri p)
 {
@@ -437,12 +436,14 @@ __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 //   uint32_t count() const;
 //   bool load(uint32_t item, V3 &e, V3 &d, double &t0, double &t1) const;  // false: nothing to trace
 //   void store(uint32_t item, bool hit, const Hit &h) const;
-// `next` is a zero-initialised device counter shared by the launch.
+// `next` is a zero-initialised device counter shared by the launch; batch_max (a multiple of 64)
+// bounds how many consecutive rays a wave reserves at a time: large batches spare the counter
+// when rays are cheap, small ones keep the rays in flight close together (cache footprint).
 //
 // The step kinds are nested loops (object phase outermost, triangle phase innermost) so that the
 // state a phase does not touch stays put in its registers while that phase repeats.
 template <int BLOCK, class Src>
-__device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t *next,
+__device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t *next, uint32_t batch_max,
                                     uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
 {
     const int tid = threadIdx.x;
@@ -451,6 +452,12 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     TravState T = {};
     TriReg A = {}, B = {};
     int mode = TM_FETCH;
+    // rays are handed to a wave in batches of 64 .. batch_max: a quarter of an even share of what is left
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    uint32_t batch = total / (nwaves * 4u);
+    batch = batch < 64u ? 64u : (batch > batch_max ? batch_max : (batch + 63u) & ~63u);
+    uint32_t wave_base = 0, wave_end = 0;
+    bool drained = false;
     for (;;) {
         // ---------------------------------------------------------------- object phase
         // Group::hit, Surface.cpp:160-181.  Lanes in OBJ mode have just finished the octree of
@@ -470,14 +477,27 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
         }
         {
             const unsigned long long need = __ballot(mode == TM_FETCH);
+            const uint32_t need_n = (uint32_t)__popcll(need), left = wave_end - wave_base;
+            uint32_t nb_base = wave_end, nb_end = wave_end;
+            if (need_n > left && !drained) {
+                // the wave's batch cannot serve every free lane: reserve another one (one atomic per
+                // batch, not per step: a counter that every wave of the launch increments
+                // serialises them).  Batches shrink as the launch runs out of rays, so that the
+                // waves finish together.
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(next, batch);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                nb_base = b < total ? b : total;
+                nb_end = (total - nb_base) < batch ? total : nb_base + batch;
+                drained = nb_end == total;
+                batch = (total - nb_end) / (nwaves * 4u);
+                batch = batch < 64u ? 64u : (batch > batch_max ? batch_max : (batch + 63u) & ~63u);
+            }
             if (mode == TM_FETCH) {
-                const uint32_t leader = (uint32_t)__ffsll((long long)need) - 1u;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(need));
-                base = __shfl(base, (int)leader, 64);
-                const uint32_t item = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (item >= total) {
-                    mode = TM_EXIT;
+                const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                const uint32_t item = rank < left ? wave_base + rank : nb_base + (rank - left);
+                if (rank >= left && item >= nb_end) {
+                    if (drained) mode = TM_EXIT;            // else: stays in FETCH until the next batch
                 } else {
                     T.item = item;
                     T.hobj = -1; T.hprim = 0; T.oi = 0;
@@ -494,13 +514,28 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     }
                 }
             }
+            if (need_n > left) {
+                const uint32_t over = need_n - left, nb = nb_end - nb_base;
+                wave_base = nb_base + (over < nb ? over : nb);
+                wave_end = nb_end;
+            } else {
+                wave_base += need_n;
+            }
+            // Scalar loads are issued well before their values are needed: the 16-byte head of
+            // the next object while this one is processed, a one-leaf mesh's first triangle
+            // together with its box, every further triangle while the previous one is tested.
             const u_object objects = (u_object)(unsigned long long)S.objects;
+            struct Head { uint32_t x, y, z, w; };                                   // {type, ntri, root, leaf_begin}
+            Head head_next = { (uint32_t)objects[0].type, objects[0].ntri, objects[0].root, objects[0].leaf_begin };
             for (int o = 0; o < S.nobjects; o++) {
+                const Head head = head_next;
+                const int on = o + 1 < S.nobjects ? o + 1 : o;
+                head_next.x = (uint32_t)objects[on].type; head_next.y = objects[on].ntri; head_next.z = objects[on].root; head_next.w = objects[on].leaf_begin;
                 const bool mine = mode == TM_OBJ && T.oi == o;
                 if (__ballot(mine) == 0ull) continue;
-                const int otype = objects[o].type;
+                const int otype = (int)head.x;
                 if (otype == RT_OBJ_MESH) {
-                    const uint32_t root = objects[o].root, ntri = objects[o].pad;
+                    const uint32_t ntri = head.y, root = head.z;
                     if (!ntri) {
                         // an octree with inner nodes: leave the sweep here (octree.cpp:312-313)
                         if (mine) { T.root = root; T.cur = root; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS; mode = TM_NODE; }
@@ -509,8 +544,9 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     // The whole octree is one leaf of ntri triangles: Octree::hit (octree.cpp:285-376)
                     // reduces to the root's slab test and OctreeNode::hit on it, and all lanes walk
                     // the same triangle list.
-                    const u_node nd = (u_node)(unsigned long long)(S.nodes + root);
-                    const V3 lo = mk(nd->lo[0], nd->lo[1], nd->lo[2]), hi = mk(nd->hi[0], nd->hi[1], nd->hi[2]);
+                    const u_leaftri P = (u_leaftri)(unsigned long long)(S.leaf_tris + head.w);
+                    TriReg tr_next = tri_load_uniform(P);
+                    const V3 lo = mk(objects[o].lo[0], objects[o].lo[1], objects[o].lo[2]), hi = mk(objects[o].hi[0], objects[o].hi[1], objects[o].hi[2]);
                     bool hb = false;
                     if (mine) {
                         double n0, n1;
@@ -518,10 +554,10 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         if (hb) { c.leaf++; c.prim += ntri; T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS; }
                     }
                     if (__ballot(hb) != 0ull) {
-                        const u_leaftri P = (u_leaftri)(unsigned long long)(S.leaf_tris + nd->obj_begin);
 #pragma unroll 1
                         for (uint32_t k = 0; k < ntri; k++) {
-                            const TriReg tr = tri_load_uniform(P + k);
+                            const TriReg tr = tr_next;
+                            tr_next = tri_load_uniform(P + (k + 1 < ntri ? k + 1 : k));
                             if (hb) tri_test(tr, T);
                         }
                         if (hb) {
@@ -695,7 +731,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(RaySrc src, uint32_t *n
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0 };
-    trace_engine<RT_BLOCK>(src.S, src, next, stk, c);
+    trace_engine<RT_BLOCK>(src.S, src, next, 128u, stk, c);
     flush_counters(counters, c);
 }
 
@@ -723,7 +759,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(PrimarySrc src, uint
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0 };
-    trace_engine<RT_BLOCK>(src.S, src, next, stk, c);
+    trace_engine<RT_BLOCK>(src.S, src, next, 128u, stk, c);
     flush_counters(counters, c);
 }
 
@@ -806,27 +842,67 @@ __device__ __forceinline__ void ray_store(const RayStack &q, uint64_t slot, V3 e
 }
 __device__ __forceinline__ double ray_f(const RayStack &q, uint64_t slot, int field) { return __longlong_as_double(q.f[(uint64_t)field * q.cap + slot]); }
 
-// Wave-aggregated append: the lanes that want a slot take consecutive ones with one atomic
-// (ballot + popcount).  Returns this lane's slot (only meaningful where want is true).
-__device__ __forceinline__ uint64_t wave_append(uint32_t *counter, bool want)
+// Class of a ray (see RayDest): does it reach the root box of an octree with inner nodes within
+// its window?  A plain single-precision slab test: the answer only decides which rays are traced
+// together, never what they return.
+__device__ __forceinline__ int ray_class(const DevScene &S, V3 e, V3 d, double t1)
 {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader, 64);
-    return (uint64_t)base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const float ex = (float)e.x, ey = (float)e.y, ez = (float)e.z;
+    const float rx = __builtin_amdgcn_rcpf((float)d.x), ry = __builtin_amdgcn_rcpf((float)d.y), rz = __builtin_amdgcn_rcpf((float)d.z);
+    const float tmax = (float)t1;
+    int cls = 0;
+    for (int b = 0; b < S.nbig; b++) {
+        const float ax = (S.big_lo[b][0] - ex) * rx, bx = (S.big_hi[b][0] - ex) * rx;
+        const float ay = (S.big_lo[b][1] - ey) * ry, by = (S.big_hi[b][1] - ey) * ry;
+        const float az = (S.big_lo[b][2] - ez) * rz, bz = (S.big_hi[b][2] - ez) * rz;
+        const float r0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        const float r1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+        if (!(r0 > r1 * 1.0001f + 1e-6f)) cls = 1;
+    }
+    return cls;
+}
+
+// Slot reservation for a block that appends rays: every wave passes its per-class totals, one
+// atomic per class and block reserves the slots, and each wave gets the first slot of its share
+// per class.  All threads of the block must call this.
+struct SlotCursor { uint64_t s[2]; };
+__device__ __forceinline__ SlotCursor block_reserve(const RayDest &D, uint32_t wave_n0, uint32_t wave_n1)
+{
+    __shared__ uint32_t wave_tot[2][RT_BLOCK / 64], block_base[2];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __syncthreads();                     // an earlier reservation of this block has been read by every wave
+    if (lane == 0) { wave_tot[0][wv] = wave_n0; wave_tot[1][wv] = wave_n1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t tot = 0;
+        for (int i = 0; i < RT_BLOCK / 64; i++) tot += wave_tot[threadIdx.x][i];
+        block_base[threadIdx.x] = tot ? atomicAdd(D.count + threadIdx.x, tot) : 0u;
+    }
+    __syncthreads();
+    SlotCursor c;
+    c.s[0] = D.base[0] + block_base[0];
+    c.s[1] = D.base[1] + block_base[1];
+    for (uint32_t i = 0; i < wv; i++) { c.s[0] += wave_tot[0][i]; c.s[1] += wave_tot[1][i]; }
+    return c;
+}
+// The lanes with `want` append one ray each (class `cls`) at the cursor and move it on.
+// m1 = ballot(want && cls), m0 = ballot(want && !cls), computed by the caller before reserving.
+__device__ __forceinline__ uint64_t take_slot(SlotCursor &c, unsigned long long m0, unsigned long long m1, int cls)
+{
+    const unsigned long long lt = (1ull << (threadIdx.x & 63u)) - 1ull;
+    const uint64_t slot = cls ? c.s[1] + (uint32_t)__popcll(m1 & lt) : c.s[0] + (uint32_t)__popcll(m0 & lt);
+    c.s[0] += (uint32_t)__popcll(m0);
+    c.s[1] += (uint32_t)__popcll(m1);
+    return slot;
 }
 
 // First rays of work items [first, first+count): item = sample-major (all pixels of sample k,
 // then k+1) so that neighbouring lanes start neighbouring pixels with the same sample index.
-__global__ __launch_bounds__(RT_BLOCK) void k_generate(WaveArgs A, RayStack q, uint64_t slot0, uint64_t first, uint32_t count)
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(DevScene S, WaveArgs A, RayDest D, uint64_t first, uint32_t count)
 {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i >= count) return;
-    const uint64_t item = first + i;
+    const bool live = i < count;
+    const uint64_t item = first + (live ? i : 0);
     V3 e, d;
     double t1;
     uint32_t pix, k;
@@ -845,7 +921,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(WaveArgs A, RayStack q, u
         camera_ray(A.cam, (float)((jx + x * 1.0) / A.width), (float)((jy + y * 1.0) / A.height), e, d);
         t1 = A.t1;
     }
-    ray_store(q, slot0 + i, e, d, t1, mk(1, 1, 1), path_root_key(A.seed, pix, k), pack_meta(pix, k, A.jumptime, 1, RAY_RADIANCE));
+    const int cls = live ? ray_class(S, e, d, t1) : 0;
+    const unsigned long long m0 = __ballot(live && !cls), m1 = __ballot(live && cls);
+    SlotCursor cur = block_reserve(D, (uint32_t)__popcll(m0), (uint32_t)__popcll(m1));
+    const uint64_t slot = take_slot(cur, m0, m1, cls);
+    if (live) ray_store(D.q[cls], slot, e, d, t1, mk(1, 1, 1), path_root_key(A.seed, pix, k), pack_meta(pix, k, A.jumptime, 1, RAY_RADIANCE));
 }
 
 // Closest hit for the chunk [base, base+count) of a ray stack.
@@ -874,11 +954,11 @@ struct StackSrc {
         q.hit_id[slot] = hit ? (((uint64_t)(uint32_t)h.obj << 32) | h.prim) : ~0ull;
     }
 };
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next)
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next, uint32_t batch_max)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0 };
-    trace_engine<RT_BLOCK>(S, src, next, stk, c);
+    trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
     flush_counters(src.A.counters, c);
 }
 
@@ -889,10 +969,8 @@ __device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
     if (v.z != 0.0) unsafeAtomicAdd(out + 3ull * pix + 2, v.z);
 }
 
-// Consume the hits of chunk [base, base+count) of `src`; follow-up rays go to `dst` at
-// dst_base + (*dst_count)++.
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayStack src, uint64_t base, uint32_t count,
-                                                     RayStack dst, uint64_t dst_base, uint32_t *dst_count)
+// Consume the hits of chunk [base, base+count) of `src`; follow-up rays are appended to D.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayStack src, uint64_t base, uint32_t count, RayDest D)
 {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = i < count;
@@ -978,8 +1056,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             }
         }
         if (li == 0) { want0 = want; ldir0 = ldir; contrib0 = contrib; dist0 = dist; continue; }
-        const uint64_t s = wave_append(dst_count, want);
-        if (want) ray_store(dst, dst_base + s, p, ldir, dist - RT_ZERO, contrib, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
+        const int cls = want ? ray_class(S, p, ldir, dist - RT_ZERO) : 0;
+        const unsigned long long m0 = __ballot(want && !cls), m1 = __ballot(want && cls);
+        SlotCursor cur = block_reserve(D, (uint32_t)__popcll(m0), (uint32_t)__popcll(m1));
+        const uint64_t slot = take_slot(cur, m0, m1, cls);
+        if (want) ray_store(D.q[cls], slot, p, ldir, dist - RT_ZERO, contrib, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
     }
 
     // ---- mirror lobe, scene.cpp:249-266
@@ -1031,35 +1112,34 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     }
     const bool wantT = lobeT && !tir;
 
-    // ---- append the follow-up rays: one slot reservation per block for the five kinds (diffuse
-    // bounce, shadow ray of light 0, mirror, reflected, refracted); a block's rays of one kind
-    // end up next to each other
+    // ---- append the follow-up rays: one slot reservation per block and class for the five kinds
+    // (diffuse bounce, shadow ray of light 0, mirror, reflected, refracted); a block's rays of one
+    // kind and class end up next to each other
     {
-        __shared__ uint32_t wave_total[RT_BLOCK / 64], block_base;
-        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned long long m0 = __ballot(lobeN), m1 = __ballot(want0), m2 = __ballot(lobeS), m3 = __ballot(lobeT), m4 = __ballot(wantT);
-        const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2), c3 = (uint32_t)__popcll(m3), c4 = (uint32_t)__popcll(m4);
-        if (lane == 0) wave_total[wv] = c0 + c1 + c2 + c3 + c4;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int i = 0; i < RT_BLOCK / 64; i++) tot += wave_total[i];
-            block_base = tot ? atomicAdd(dst_count, tot) : 0u;
-        }
-        __syncthreads();
-        uint64_t s = dst_base + block_base;
-        for (uint32_t i = 0; i < wv; i++) s += wave_total[i];
-        if (lobeN) ray_store(dst, s + (uint32_t)__popcll(m0 & lt), p, dn, RT_INFINITE, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0, RAY_RADIANCE));
-        s += c0;
-        if (want0) ray_store(dst, s + (uint32_t)__popcll(m1 & lt), p, ldir0, dist0 - RT_ZERO, contrib0, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
-        s += c1;
-        if (lobeS) ray_store(dst, s + (uint32_t)__popcll(m2 & lt), p, md, RT_INFINITE, had(W, mcolor), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
-        s += c2;
+        const int k0 = lobeN ? ray_class(S, p, dn, RT_INFINITE) : 0;
+        const int k1 = want0 ? ray_class(S, p, ldir0, dist0 - RT_ZERO) : 0;
+        const int k2 = lobeS ? ray_class(S, p, md, RT_INFINITE) : 0;
+        const int k3 = lobeT ? ray_class(S, p, r, RT_INFINITE) : 0;
+        const int k4 = wantT ? ray_class(S, p, rfr, RT_INFINITE) : 0;
+        const unsigned long long a0 = __ballot(lobeN && !k0), b0 = __ballot(lobeN && k0);
+        const unsigned long long a1 = __ballot(want0 && !k1), b1 = __ballot(want0 && k1);
+        const unsigned long long a2 = __ballot(lobeS && !k2), b2 = __ballot(lobeS && k2);
+        const unsigned long long a3 = __ballot(lobeT && !k3), b3 = __ballot(lobeT && k3);
+        const unsigned long long a4 = __ballot(wantT && !k4), b4 = __ballot(wantT && k4);
+        SlotCursor cur = block_reserve(D, (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2) + __popcll(a3) + __popcll(a4)),
+                                       (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4)));
+        uint64_t slot;
+        slot = take_slot(cur, a0, b0, k0);
+        if (lobeN) ray_store(D.q[k0], slot, p, dn, RT_INFINITE, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0, RAY_RADIANCE));
+        slot = take_slot(cur, a1, b1, k1);
+        if (want0) ray_store(D.q[k1], slot, p, ldir0, dist0 - RT_ZERO, contrib0, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
+        slot = take_slot(cur, a2, b2, k2);
+        if (lobeS) ray_store(D.q[k2], slot, p, md, RT_INFINITE, had(W, mcolor), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
         // reflected ray: weight k (total internal reflection) or k*R
-        if (lobeT) ray_store(dst, s + (uint32_t)__popcll(m3 & lt), p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
-        s += c3;
-        if (wantT) ray_store(dst, s + (uint32_t)__popcll(m4 & lt), p, rfr, RT_INFINITE, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        slot = take_slot(cur, a3, b3, k3);
+        if (lobeT) ray_store(D.q[k3], slot, p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        slot = take_slot(cur, a4, b4, k4);
+        if (wantT) ray_store(D.q[k4], slot, p, rfr, RT_INFINITE, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
     }
 
     if (live) add_radiance(A.out, pix, sum);
@@ -1118,26 +1198,27 @@ hipError_t launch_trace_primary(const DevScene &S, int num_cu, uint32_t *next, c
     hipLaunchKernelGGL(k_trace_primary, dim3(engine_blocks((uint64_t)w * h, num_cu, (const void *)k_trace_primary)), dim3(RT_BLOCK), 0, st, src, next, counters);
     return hipGetLastError();
 }
-hipError_t launch_generate(const WaveArgs &A, const RayStack &q, uint64_t slot0, uint64_t first, uint32_t count, hipStream_t st)
+hipError_t launch_generate(const DevScene &S, const WaveArgs &A, const RayDest &dst, uint64_t first, uint32_t count, hipStream_t st)
 {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_generate, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, A, q, slot0, first, count);
+    hipLaunchKernelGGL(k_generate, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, dst, first, count);
     return hipGetLastError();
 }
-hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count, hipStream_t st)
+hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
+                        int ray_class, hipStream_t st)
 {
     if (!count) return hipSuccess;
     StackSrc src = { A, q, base, count };
     hipError_t e = hipMemsetAsync(next, 0, 4, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next);
+    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next, ray_class ? 128u : 1024u);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
-                        const RayStack &dst, uint64_t dst_base, uint32_t *dst_count, hipStream_t st)
+                        const RayDest &dst, hipStream_t st)
 {
     if (!count) return hipSuccess;
-    hipLaunchKernelGGL(k_shade, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, src, base, count, dst, dst_base, dst_count);
+    hipLaunchKernelGGL(k_shade, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, src, base, count, dst);
     return hipGetLastError();
 }
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st)
