@@ -330,7 +330,8 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
     if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
     if (total_items == 0) return 0;
     const uint64_t max_push = (uint64_t)s->max_push;
-    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", 4u << 20);        // rays per round
+    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", 16u << 20);       // rays per round: large rounds keep the persistent grid
+                                                                     // busy (20 and more rays per lane) and cost only stack memory
     if (target > total_items * max_push) target = total_items * max_push;
     if (target < RT_BLOCK) target = RT_BLOCK;
     const uint64_t cap = target * (max_push + 3);
