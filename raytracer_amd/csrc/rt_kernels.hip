@@ -970,6 +970,9 @@ __device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
 }
 
 // Consume the hits of chunk [base, base+count) of `src`; follow-up rays are appended to D.
+#ifdef RT_SHADE_WAVES
+__attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+#endif
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayStack src, uint64_t base, uint32_t count, RayDest D)
 {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;

@@ -13,7 +13,7 @@ import pytest
 
 from oracle import orc
 from raytracer_amd import hip, scenes
-from raytracer_amd.desc import (LIGHT_DT, MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MATERIAL_DT, MISS, OBJECT_DT, RAY_DT,
+from raytracer_amd.desc import (LIGHT_DT, MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MATERIAL_DT, MISS, OBJ_GROUND, OBJECT_DT, RAY_DT,
                                 SceneDesc, render_params)
 
 pytestmark = pytest.mark.gpu
@@ -300,6 +300,52 @@ def test_camera_inside_mesh_and_axis_aligned_rays():
     p2, t2, n2, c2 = sg.trace_rays(rays, 1e-9, 1e10)
     assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
     assert (p1 != MISS).mean() > 0.6
+
+
+def test_two_large_meshes_between_simple_objects():
+    """Object order sphere, large mesh, one-leaf mesh, plane, large mesh, sphere: every kind of
+    hand-over between the object sweep and the octree steps, for closest hits and for path tracing."""
+    a = scenes.blob((30, 30, 40), 18.0, 30, 31, seed=2)
+    b = scenes.blob((70, 35, 55), 20.0, 28, 29, seed=3)
+    small = scenes.quad((10, 0.5, 10), (90, 0.5, 10), (90, 0.5, 90), (10, 0.5, 90))
+    mats = [scenes.material(MAT_NORMAL, color=(.7, .6, .5)), scenes.material(MAT_SPECULAR, color=(.9, .9, .9)),
+            scenes.material(MAT_TRANSPARENT, color=(.95, .95, .95), atten=(.01, .02, .03), nr=1.4),
+            scenes.material(MAT_NORMAL, emission=(20, 20, 20), color=(0, 0, 0))]
+    objs = [scenes.sphere((50, 12, 30), 10.0, 1), scenes.mesh_object(0, 0), scenes.mesh_object(2, 0), scenes.plane(OBJ_GROUND, 0.0, 0),
+            scenes.mesh_object(1, 2), scenes.sphere((50, 90, 50), 8.0, 3)]
+    lights = [scenes.sphere_light((50, 90, 50), 8.0, (20, 20, 20))]
+    desc = SceneDesc(scenes._stack(objs, OBJECT_DT), scenes._stack(mats, MATERIAL_DT), scenes._stack(lights, LIGHT_DT),
+                     [a, b, small], background=(.1, .1, .12))
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    assert so.octree_stats(0) == sg.octree_stats(0) and sg.octree_stats(0)["nodes"] > 1 and sg.octree_stats(2)["nodes"] == 1
+    rays = _rays(np.random.default_rng(5), 40000, 0.0, 100.0)
+    d = np.random.default_rng(6).uniform(5, 95, (len(rays), 3)) - rays["e"]      # aim at the scene, keep the exact zeros
+    rays["d"] = np.where(rays["d"] == 0.0, 0.0, d / np.linalg.norm(d, axis=1, keepdims=True))
+    p1, t1, n1, c1 = so.trace_rays(rays, 1e-9, 1e10)
+    p2, t2, n2, c2 = sg.trace_rays(rays, 1e-9, 1e10)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
+    assert (p1 != MISS).mean() > 0.5
+    c = hip.camera_init((50, 45, 230), (50, 35, 50), (0, 1, 0), 35, 1.0)
+    prm = render_params(64, 64, 2, seed=12, max_jump=20)
+    i1, k1 = so.render(c, prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2) and _rel(i1, i2).max() <= PATH_RTOL
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e60, 1e101])
+def test_scaled_scene_bit_exact(scale):
+    """Coordinates far from 1: up to 1e100 the slab tests use the reciprocal form, beyond it true
+    divisions; both must reproduce the oracle bit for bit."""
+    tris = scenes.soup(3000, seed=41, edge_lo=2e-2, edge_hi=2e-1) * scale
+    desc = _mesh_desc(tris, octree_max_size=16, octree_max_depth=15, tri_box_pad=1e-7 * scale)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    assert so.octree_stats(0) == sg.octree_stats(0)
+    rays = _rays(np.random.default_rng(42), 20000, -0.5, 1.5)
+    rays["e"] *= scale
+    p1, t1, n1, c1 = so.trace_rays(rays, 0.0, 1e10 * scale)
+    p2, t2, n2, c2 = sg.trace_rays(rays, 0.0, 1e10 * scale)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
+    assert (p1 != MISS).mean() > 0.2
 
 
 def test_profile_counters_are_consistent():
