@@ -122,6 +122,32 @@ int rt_scene_destroy(rt_scene *s)
     return 0;
 }
 
+// Bounding sphere of the triangle (v0, v0+e1, v0+e2) for the kernels' single-precision
+// pre-test: centre = centroid, radius = largest vertex distance, then inflated by 1e-5 of
+// itself plus 4e-7 of the centre's coordinate magnitudes (the rounding of the centre and of
+// the ray origin to float) and rounded up.  Anything not finite in float becomes an infinite
+// radius (the pre-test then always passes).
+static LeafSphere make_leaf_sphere(const LeafTri &t)
+{
+    double v[3][3], c[3];
+    for (int k = 0; k < 3; k++) { v[0][k] = t.v0[k]; v[1][k] = t.v0[k] + t.e1[k]; v[2][k] = t.v0[k] + t.e2[k]; }
+    for (int k = 0; k < 3; k++) c[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
+    double r2 = 0;
+    for (int i = 0; i < 3; i++) {
+        double d2 = 0;
+        for (int k = 0; k < 3; k++) d2 += (v[i][k] - c[k]) * (v[i][k] - c[k]);
+        if (!(d2 <= r2)) r2 = d2;
+    }
+    const double r = std::sqrt(r2) * (1.0 + 1e-5) + 4e-7 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
+    LeafSphere s;
+    s.x = (float)c[0]; s.y = (float)c[1]; s.z = (float)c[2];
+    s.r = std::nextafter((float)r, INFINITY);
+    if (!std::isfinite(s.x) || !std::isfinite(s.y) || !std::isfinite(s.z) || !std::isfinite(s.r) || !(r == r)) {
+        s.x = s.y = s.z = 0.0f; s.r = INFINITY;
+    }
+    return s;
+}
+
 int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
 {
     if (!d || !out) return fail("rt_scene_create: null argument");
@@ -211,13 +237,15 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     }
     std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
     std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
-    void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr;
+    std::vector<LeafSphere> leaf_sph(leaf_tris.size());
+    for (size_t i = 0; i < leaf_tris.size(); i++) leaf_sph[i] = make_leaf_sphere(leaf_tris[i]);
+    void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
     auto up = [&](auto &vec, void **dst) {
         if (e != hipSuccess) return;
         e = upload(vec, dst);
         if (*dst) s->allocs.push_back(*dst);
     };
-    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tris, &p_tris);
+    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tris, &p_tris); up(leaf_sph, &p_sph);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
     if (e != hipSuccess) { rt_scene_destroy(s); return fail_hip("scene upload", e); }
@@ -226,6 +254,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.lights = (const rt_light *)p_light;
     s->dev.nodes = (const FlatNode *)p_nodes;
     s->dev.leaf_tris = (const LeafTri *)p_idx;
+    s->dev.leaf_sph = (const LeafSphere *)p_sph;
     s->dev.tris = (const double *)p_tris;
     s->dev.nobjects = (int32_t)d->nobjects;
     s->dev.nlights = (int32_t)d->nlights;

@@ -7,6 +7,11 @@
 
 namespace rt {
 
+// Single-precision sphere around one triangle record, inflated so that a single-precision
+// test of a ray against it can never reject a ray that the fp64 triangle test accepts (see
+// make_leaf_sphere).  16 bytes: one load per triangle instead of five.
+struct LeafSphere { float x, y, z, r; };
+
 // One Group child as the kernels see it.  The object phase of the closest-hit engine reads
 // this table at wave-uniform addresses (scalar loads); a record carries everything that phase
 // needs for the object so that no dependent look-up follows: the first 16 bytes say what to do,
@@ -32,6 +37,7 @@ struct DevScene {
     const rt_light    *lights;
     const FlatNode    *nodes;      // all meshes' nodes, 64-byte records
     const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
+    const LeafSphere  *leaf_sph;   // one bounding sphere per leaf_tris record (same index)
     const double      *tris;       // v0, e1, e2 (9 doubles) by global triangle index, for shading normals
     int32_t nobjects;
     int32_t nlights;

@@ -284,6 +284,9 @@ struct TravState {
     uint32_t k, kend, bprim;
     double bt0, tempt;
     bool leaf;
+    // pre-tested triangles waiting for the fp64 test: bit j of pend = record pbase + j;
+    // cand = the record requested in the previous step (RT_MISS: none)
+    uint32_t pend, pbase, cand;
 };
 
 // hitBox for a ray with regular direction: same values as hit_box (FAST node steps, above)
@@ -416,15 +419,50 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     }
 }
 
-// A lane that has just opened a triangle run loads its first two records; after that every
-// triangle step tests records k and k+1 and refills the two register sets with k+2 and k+3,
-// so a record is always requested one step before it is needed.
-__device__ __forceinline__ void run_open(const DevScene &S, const TravState &T, TriReg &A, TriReg &B)
+// Triangle runs are walked four records per step with a cheap pre-test: a single-precision
+// test of the ray against the record's bounding sphere (16 bytes, one load) decides whether the
+// 80-byte record is fetched and the fp64 test made at all.  The sphere is inflated at build time
+// and the test carries margins for every single-precision rounding (ray origin, direction, the
+// cancellation in c2 - b^2/dd), so it only ever rejects rays that pass the triangle at a clear
+// distance: the fp64 test, which accepts rays within ~1e-15 of the triangle, would reject them
+// too.  A NaN or an overflow anywhere makes the pre-test pass.  The fetch path of the vector
+// memory pipeline handles one lane's load per clock when lanes read unrelated addresses, and
+// that, not arithmetic, bounds triangle steps: 1 + (few) loads per triangle instead of 5.
+struct RayF { float ex, ey, ez, dx, dy, dz, inv_dd, slack; };
+__device__ __forceinline__ RayF ray_single(V3 e, V3 d)
 {
-    const LeafTri *P = S.leaf_tris + T.k;
-    A = tri_load(P);
-    __builtin_amdgcn_sched_barrier(0);      // keep A's loads older than B's: the first triangle step waits for A only
-    B = tri_load(P + (T.k + 1 < T.kend ? 1 : 0));
+    RayF r;
+    r.ex = (float)e.x; r.ey = (float)e.y; r.ez = (float)e.z;
+    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
+    r.inv_dd = 1.0f / __builtin_fmaf(r.dx, r.dx, __builtin_fmaf(r.dy, r.dy, r.dz * r.dz));
+    r.slack = 4e-7f * (fabsf(r.ex) + fabsf(r.ey) + fabsf(r.ez));
+    return r;
+}
+__device__ __forceinline__ LeafSphere sph_load(const LeafSphere *p)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    LeafSphere s; s.x = v.x; s.y = v.y; s.z = v.z; s.r = v.w;
+    return s;
+}
+__device__ __forceinline__ bool sph_pass(const LeafSphere &s, const RayF &r)
+{
+    const float ox = s.x - r.ex, oy = s.y - r.ey, oz = s.z - r.ez;
+    const float b = __builtin_fmaf(ox, r.dx, __builtin_fmaf(oy, r.dy, oz * r.dz));
+    const float c2 = __builtin_fmaf(ox, ox, __builtin_fmaf(oy, oy, oz * oz));
+    const float perp2 = __builtin_fmaf(-(b * r.inv_dd), b, c2);          // squared distance of the centre from the ray's line
+    const float R = s.r + r.slack;
+    const float bound = __builtin_fmaf(R, R, 4e-6f * c2);
+    return !(perp2 > bound);
+}
+// A lane that has just opened a triangle run loads the spheres of its first four records (a
+// run shorter than four repeats its last record; the repeats are masked out when tested).
+__device__ __forceinline__ void run_open(const DevScene &S, TravState &T, LeafSphere (&Q)[4])
+{
+    const LeafSphere *P = S.leaf_sph + T.k;
+    const uint32_t last = T.kend - T.k - 1u;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + (i < last ? i : last));
+    T.pend = 0; T.cand = RT_MISS;
 }
 __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 {
@@ -450,7 +488,8 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
     TravState T = {};
-    TriReg A = {}, B = {};
+    TriReg R = {};
+    LeafSphere Q[4] = {};
     int mode = TM_FETCH;
     // rays are handed to a wave in batches of 64 .. batch_max: a quarter of an even share of what is left
     const uint32_t nwaves = gridDim.x * (BLOCK / 64);
@@ -615,7 +654,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 const bool in = mode == TM_NODE;
                 if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, c); }
                 else { if (in) node_step<false, BLOCK>(S, T, mode, stk, c); }
-                if (in && mode == TM_TRI) run_open(S, T, A, B);
+                if (in && mode == TM_TRI) run_open(S, T, Q);
                 continue;
             }
             // ------------------------------------------------------------ triangle steps
@@ -624,20 +663,35 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 c.prim += 1;
 #endif
                 if (mode == TM_TRI) {
-                    const LeafTri *P = S.leaf_tris + T.k;
-                    const uint32_t left = T.kend - T.k;                  // >= 1
-                    // the refills are unconditional (a run that is about to end re-reads its current
-                    // record) so that this stays straight-line code with exact load counting
-                    tri_test(A, T);
-                    A = tri_load(P + (left > 2 ? 2 : 0));
-                    tri_test(B, T);            // left == 1: B is a copy of the run's last record, testing it again changes nothing
-                    B = tri_load(P + (left > 3 ? 3 : 0));
-                    const uint32_t adv = left > 1 ? 2u : 1u;
-                    T.k += adv;
+                    // 1. the fp64 test of the record requested in the previous step
+                    if (T.cand != RT_MISS) { tri_test(R, T); T.cand = RT_MISS; }
+                    // 2. pre-test the next four records, unless earlier ones still wait for their turn
+                    if (T.pend == 0u && T.k < T.kend) {
+                        const RayF rf = ray_single(T.e, T.d);
+                        const uint32_t left = T.kend - T.k, take = left < 4u ? left : 4u;
+                        uint32_t m = 0;
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) m |= sph_pass(Q[i], rf) ? 1u << i : 0u;
+                        T.pend = m & ((1u << take) - 1u);
+                        T.pbase = T.k;
+                        T.k += take;
 #if RT_STEP_STATS != 1
-                    c.prim += adv;
+                        c.prim += take;
 #endif
-                    if (left <= 2) {
+                        // the spheres of the four records after these (clamped to the run's last record)
+                        const uint32_t last = T.kend > T.k ? T.kend - T.k - 1u : 0u;
+                        const LeafSphere *P = S.leaf_sph + (T.kend > T.k ? T.k : T.kend - 1u);
+#pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + (i < last ? i : last));
+                    }
+                    // 3. request the first waiting record (candidates are tested in list order, so
+                    //    "the last equal hit wins", octree.cpp:31, is kept)
+                    if (T.pend != 0u) {
+                        const uint32_t j = (uint32_t)__ffs((int)T.pend) - 1u;
+                        T.pend &= T.pend - 1u;
+                        T.cand = T.pbase + j;
+                        R = tri_load(S.leaf_tris + T.cand);
+                    } else if (T.k >= T.kend) {
                         bool improved = false;
                         if (T.bprim != RT_MISS && T.tempt < T.mint) { T.mint = T.tempt; T.minprim = T.bprim; improved = true; }   // octree.cpp:320-325
                         mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
