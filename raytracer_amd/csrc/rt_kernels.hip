@@ -434,7 +434,7 @@ __device__ __forceinline__ RayF ray_single(V3 e, V3 d)
     RayF r;
     r.ex = (float)e.x; r.ey = (float)e.y; r.ez = (float)e.z;
     r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
-    r.inv_dd = 1.0f / __builtin_fmaf(r.dx, r.dx, __builtin_fmaf(r.dy, r.dy, r.dz * r.dz));
+    r.inv_dd = __builtin_amdgcn_rcpf(__builtin_fmaf(r.dx, r.dx, __builtin_fmaf(r.dy, r.dy, r.dz * r.dz)));   // 1 ulp, inside the margins
     r.slack = 4e-7f * (fabsf(r.ex) + fabsf(r.ey) + fabsf(r.ez));
     return r;
 }
