@@ -349,7 +349,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         mode = TM_OBJ;                                     // this octree is finished
         return;
     }
-#ifndef RT_STEP_STATS
+#if !defined(RT_STEP_STATS)
     if (child_base) c.inner++; else c.leaf++;
 #else
     if (RT_STEP_STATS == 2 && !child_base) c.leaf++;
@@ -497,6 +497,15 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     batch = batch < 64u ? 64u : (batch > batch_max ? batch_max : (batch + 63u) & ~63u);
     uint32_t wave_base = 0, wave_end = 0;
     bool drained = false;
+#if RT_STEP_STATS == 4
+    // clock ticks (/16) per phase, lane 0 of every wave: rays = object phases, inner = node steps,
+    // leaf = triangle steps, prim = the wave's whole life
+    long long tk0 = clock64();
+    const long long tk_start = tk0;
+#define RT_TICK(field) { const long long tk1 = clock64(); if (lane == 0) c.field += (uint32_t)((tk1 - tk0) >> 4); tk0 = tk1; }
+#else
+#define RT_TICK(field)
+#endif
     for (;;) {
         // ---------------------------------------------------------------- object phase
         // Group::hit, Surface.cpp:160-181.  Lanes in OBJ mode have just finished the octree of
@@ -590,7 +599,12 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     if (mine) {
                         double n0, n1;
                         hb = T.fast ? hit_box_fast(lo, hi, T.e, T.d, T.r, T.t0, T.t1, n0, n1) : hit_box(lo, hi, T.e, T.d, T.t0, T.t1, n0, n1);
-                        if (hb) { c.leaf++; c.prim += ntri; T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS; }
+                        if (hb) {
+#if !defined(RT_STEP_STATS) || RT_STEP_STATS < 3
+                            c.leaf++; c.prim += ntri;
+#endif
+                            T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
+                        }
                     }
                     if (__ballot(hb) != 0ull) {
 #pragma unroll 1
@@ -623,6 +637,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 mode = TM_FETCH;
             }
         }
+        RT_TICK(rays)
         // ------------------------------------------- node and triangle steps until the next object step
         bool finished = false;
         for (;;) {
@@ -655,12 +670,19 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, c); }
                 else { if (in) node_step<false, BLOCK>(S, T, mode, stk, c); }
                 if (in && mode == TM_TRI) run_open(S, T, Q);
+                RT_TICK(inner)
                 continue;
             }
             // ------------------------------------------------------------ triangle steps
             for (;;) {
 #if RT_STEP_STATS == 1
                 c.prim += 1;
+#elif RT_STEP_STATS == 3
+                {   // triangle steps (rays), and the lanes in each state at those steps
+                    const uint32_t sT = (uint32_t)__popcll(__ballot(mode == TM_TRI)), sN = (uint32_t)__popcll(__ballot(mode == TM_NODE || mode == TM_POP));
+                    const uint32_t sO = (uint32_t)__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH));
+                    if (lane == 0) { c.rays += 1; c.inner += sT; c.leaf += sN; c.prim += sO; }
+                }
 #endif
                 if (mode == TM_TRI) {
                     // 1. the fp64 test of the record requested in the previous step
@@ -675,7 +697,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         T.pend = m & ((1u << take) - 1u);
                         T.pbase = T.k;
                         T.k += take;
-#if RT_STEP_STATS != 1
+#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4
                         c.prim += take;
 #endif
                         // the spheres of the four records after these (clamped to the run's last record)
@@ -702,9 +724,13 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) * RT_WN >= nT) break;
                 if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) * RT_WO >= nT) break;
             }
+            RT_TICK(leaf)
         }
         if (finished) break;
     }
+#if RT_STEP_STATS == 4
+    if (lane == 0) c.prim += (uint32_t)((clock64() - tk_start) >> 4);
+#endif
 }
 
 // Drawable::doAfterHit -> getRawNormal (Surface.cpp:228-231, 68-71; Surface.h:184,197,211);
@@ -1048,11 +1074,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         else if (!hit) sum = had(W, ld3(S.background));                      // scene.cpp:196-198, 378-380
         else shade = true;
     }
-    // values every push site needs
-    const V3 re = mk(ray_f(src, slot, RAY_EX), ray_f(src, slot, RAY_EY), ray_f(src, slot, RAY_EZ));
-    const V3 rd = mk(ray_f(src, slot, RAY_DX), ray_f(src, slot, RAY_DY), ray_f(src, slot, RAY_DZ));
-    const uint64_t key = src.f[(uint64_t)RAY_KEY * src.cap + slot];
-    const double ht = src.hit_t[slot];
+    // values every push site needs; shadow rays and misses (about half of all rays, and whole
+    // waves of them, since rays of one kind are appended next to each other) skip these loads
+    V3 re = mk(0, 0, 0), rd = mk(0, 0, 1);
+    uint64_t key = 0;
+    double ht = 0;
+    if (shade) {
+        re = mk(ray_f(src, slot, RAY_EX), ray_f(src, slot, RAY_EY), ray_f(src, slot, RAY_EZ));
+        rd = mk(ray_f(src, slot, RAY_DX), ray_f(src, slot, RAY_DY), ray_f(src, slot, RAY_DZ));
+        key = src.f[(uint64_t)RAY_KEY * src.cap + slot];
+        ht = src.hit_t[slot];
+    }
     const int jt = jump + 1;
     Hit h; h.t = ht; h.obj = (int32_t)(id >> 32); h.prim = (uint32_t)id;
     if (!shade) { h.obj = 0; h.prim = 0; }
