@@ -28,8 +28,8 @@ enum { RT_MAT_NORMAL = 1, RT_MAT_SPECULAR = 2, RT_MAT_TRANSPARENT = 4, RT_MAT_MO
 /* Node kinds -- Surface.h:50-56; RT_OBJ_MESH is the triangle mesh drawable this library adds
  * where the reference has HeartShape / ImplicitSurface (Surface.h:131-174) */
 enum { RT_OBJ_SPHERE = 1, RT_OBJ_GROUND = 2, RT_OBJ_WALL_Z = 3, RT_OBJ_WALL_X = 4, RT_OBJ_MESH = 5 };
-/* SphereLight / FaceLight -- light.h:32-73 */
-enum { RT_LIGHT_SPHERE = 1, RT_LIGHT_FACE = 2 };
+/* SphereLight / FaceLight / the point Light -- light.h:8-73 */
+enum { RT_LIGHT_SPHERE = 1, RT_LIGHT_FACE = 2, RT_LIGHT_POINT = 3 };
 
 #define RT_MISS 0xFFFFFFFFu
 
@@ -42,18 +42,26 @@ typedef struct {
     double  p[4];      /* Sphere(center, radius): cx,cy,cz,r (Surface.h:98) ; Ground(y) / Wall_z(z) / Wall_x(x): p[0] */
 } rt_object;
 
-/* Plain Monte-Carlo Material -- material.h:55-66, ctors material.cpp:14-23 */
+/* Plain Material -- material.h:55-66, ctors material.cpp:2-23.  With RT_MAT_MONTECARLO in
+ * `type` the Monte-Carlo branch of Scene::rayColor shades the hit (scene.cpp:205-304), without
+ * it the Phong / Whitted branch (scene.cpp:305-375), which reads the last four fields. */
 typedef struct {
     int32_t type;
     int32_t reserved;
     double  emission[3];
-    double  color[3];  /* getColor() == diffuse */
-    double  blur;      /* getMirrorBlur() */
-    double  atten[3];  /* getAttenuation() */
-    double  nr;        /* getRefraCoef() */
+    double  color[3];    /* getColor() == getDiffuse() */
+    double  blur;        /* getMirrorBlur() */
+    double  atten[3];    /* getAttenuation() */
+    double  nr;          /* getRefraCoef() */
+    double  ambient[3];  /* getAmbient() */
+    double  specular[3]; /* getSpecular() */
+    double  mirror[3];   /* getMirror() */
+    double  shine;       /* getShine() */
 } rt_material;
 
-/* SphereLight(pos, radius, emission) light.cpp:109-116 ; FaceLight(...) light.cpp:50-56 */
+/* SphereLight(pos, radius, emission) light.cpp:109-116 ; FaceLight(...) light.cpp:50-56 ;
+ * Light(pos, ambient, diffuse, specular) light.cpp:8-11 (RT_LIGHT_POINT: no geometry, pos only).
+ * ambient / specular are read by the Phong branch only (scene.cpp:308-320). */
 typedef struct {
     int32_t type;
     int32_t reserved;
@@ -64,6 +72,8 @@ typedef struct {
     double  right[3];       /* up ^ normal, not normalised */
     double  width, height;
     double  diffuse[3];     /* getDiffuse() */
+    double  ambient[3];     /* getAmbient() */
+    double  specular[3];    /* getSpecular() */
 } rt_light;
 
 typedef struct {

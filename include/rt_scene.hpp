@@ -49,6 +49,18 @@ using Color = Vec4;
 class Material {
 public:
     enum Type { NULLTYPE = 0x0, NORMAL = 0x1, SPECULAR = 0x2, TRANSPARENT = 0x4, MONTECARLO = 0x8 };
+    Material(Color amb, Color dif, Color spe, double shi)                    // material.cpp:2-6
+    {
+        rec_ = rt_material{};
+        rec_.type = NORMAL;
+        set3(rec_.ambient, amb); set3(rec_.color, dif); set3(rec_.specular, spe); rec_.shine = shi;
+    }
+    Material(Color amb, Color dif, Color spe, Color mir, double shi)         // material.cpp:8-12
+    {
+        rec_ = rt_material{};
+        rec_.type = SPECULAR | NORMAL;
+        set3(rec_.ambient, amb); set3(rec_.color, dif); set3(rec_.specular, spe); set3(rec_.mirror, mir); rec_.shine = shi;
+    }
     Material(Color emission, Color color, Type type)                         // material.cpp:14-17
     {
         rec_ = rt_material{};
@@ -175,10 +187,23 @@ private:
 
 class Light {                                                                // light.h:8-30
 public:
+    Light() = default;
+    Light(Vec3 pos, Color ambient, Color diffuse, Color specular)             // light.cpp:8-11
+    {
+        rec_.type = RT_LIGHT_POINT;
+        rec_.pos[0] = pos.x_; rec_.pos[1] = pos.y_; rec_.pos[2] = pos.z_;
+        set_colors(ambient, diffuse, specular);
+    }
     virtual ~Light() = default;
     virtual std::shared_ptr<Drawable> getGeometry() { return nullptr; }
     const rt_light &record() const { return rec_; }
 protected:
+    void set_colors(const Color &a, const Color &d, const Color &sp)
+    {
+        rec_.ambient[0] = a.x_; rec_.ambient[1] = a.y_; rec_.ambient[2] = a.z_;
+        rec_.diffuse[0] = d.x_; rec_.diffuse[1] = d.y_; rec_.diffuse[2] = d.z_;
+        rec_.specular[0] = sp.x_; rec_.specular[1] = sp.y_; rec_.specular[2] = sp.z_;
+    }
     rt_light rec_{};
 };
 class SphereLight : public Light {                                           // light.cpp:109-116
@@ -197,7 +222,7 @@ private:
 };
 class FaceLight : public Light {                                             // light.cpp:50-56
 public:
-    FaceLight(Vec3 pos, Vec3 normal, Vec3 up, double width, double height, Color /*ambient*/, Color diffuse, Color /*specular*/)
+    FaceLight(Vec3 pos, Vec3 normal, Vec3 up, double width, double height, Color ambient, Color diffuse, Color specular)
     {
         rec_.type = RT_LIGHT_FACE;
         const Vec3 right = up ^ normal, n = normal.normalize();
@@ -206,7 +231,7 @@ public:
         rec_.up[0] = up.x_; rec_.up[1] = up.y_; rec_.up[2] = up.z_;
         rec_.right[0] = right.x_; rec_.right[1] = right.y_; rec_.right[2] = right.z_;
         rec_.width = width; rec_.height = height;
-        rec_.diffuse[0] = diffuse.x_; rec_.diffuse[1] = diffuse.y_; rec_.diffuse[2] = diffuse.z_;
+        set_colors(ambient, diffuse, specular);
     }
 };
 

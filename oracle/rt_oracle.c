@@ -648,6 +648,11 @@ static v3 first_intersection_sphere(ray_t ray, v3 center, double radius, double 
 static v3 light_sample(const orc_light *l, v3 ppos, double ru, double rv, v3 *normal, double *p)
 {
     v3 pos_ = v3p(l->pos);
+    if (l->type == ORC_LIGHT_POINT) {                      /* Light::getPosition, light.cpp:37-41: the normal stays (0,0,0) */
+        *p = 1;
+        *normal = V(0, 0, 0);
+        return pos_;
+    }
     if (l->type == ORC_LIGHT_FACE) {                       /* FaceLight::getPosition, light.cpp:76-86 */
         v3 pos = pos_;
         pos = vadd(pos, vadd(vmul(vmul(v3p(l->right), ru - 0.5), l->width), vmul(vmul(v3p(l->up), rv - 0.5), l->height)));
@@ -713,7 +718,7 @@ typedef struct {
     counters_t *c;
 } pctx;
 
-/* Scene::rayColor, Monte-Carlo branch, scene.cpp:194-304 */
+/* Scene::rayColor, scene.cpp:194-381 */
 static v3 ray_color(const pctx *cx, ray_t ray, double t0, double t1, int jumpTime, int E, uint64_t key)
 {
     const orc_scene *s = cx->s;
@@ -726,7 +731,87 @@ static v3 ray_color(const pctx *cx, ray_t ray, double t0, double t1, int jumpTim
     v3 color = V(0, 0, 0);
     v3 emission = v3p(mat->emission), mcolor = v3p(mat->color);
     double Ed = (double)E;
-    if (!(mat->type & ORC_MAT_MONTECARLO)) return color; /* legacy Phong branch: out of scope */
+    if (!(mat->type & ORC_MAT_MONTECARLO)) {
+        /* Phong / Whitted branch, scene.cpp:305-375 */
+        if (mat->type & ORC_MAT_NORMAL) {                                /* :307-322 */
+            for (uint64_t li = 0; li < s->nlights; li++) {
+                const orc_light *L = &s->lights[li];
+                color = vadd(color, V(L->ambient[0] * mat->ambient[0], L->ambient[1] * mat->ambient[1], L->ambient[2] * mat->ambient[2]));
+                /* light->getPosition() without a hit record: the point itself, a jittered point of
+                 * a FaceLight; a SphereLight would dereference the null record (light.cpp:143) and
+                 * is taken at its centre here */
+                v3 lightpos = v3p(L->pos);
+                if (L->type == ORC_LIGHT_FACE) { v3 nn; double pp; lightpos = light_sample(L, p, cx->light_uv[2 * li], cx->light_uv[2 * li + 1], &nn, &pp); }
+                ray_t nr;
+                nr.e = p;
+                nr.d = vnorm(vsub(lightpos, p));
+                if (!group_hit(s, nr, RT_ZERO, vlen(vsub(lightpos, p)) - RT_ZERO, NULL, cx->c)) {
+                    double kd = vdot(rec.normal, nr.d);
+                    if (!(0.0 < kd)) kd = 0.0;                           /* max(0.0, n.d) */
+                    color = vadd(color, V(mat->color[0] * (L->diffuse[0] * kd), mat->color[1] * (L->diffuse[1] * kd), mat->color[2] * (L->diffuse[2] * kd)));
+                    double ks = pow(vdot(vnorm(vsub(nr.d, ray.d)), rec.normal), mat->shine);
+                    color = vadd(color, V(mat->specular[0] * (L->specular[0] * ks), mat->specular[1] * (L->specular[1] * ks), mat->specular[2] * (L->specular[2] * ks)));
+                }
+            }
+        }
+        if (mat->type & ORC_MAT_SPECULAR) {                              /* :324-341 */
+            ray_t mr;
+            mr.e = p;
+            mr.d = vsub(ray.d, vmul(vmul(rec.normal, vdot(rec.normal, ray.d)), 2));
+            if (mat->blur >= RT_ZERO) {
+                v3 vec = V(0, 0, 1);
+                if (viszero(vcross(vec, mr.d))) vec = V(0, 1, 0);
+                v3 u = vnorm(vcross(vec, mr.d));
+                v3 v = vnorm(vcross(mr.d, u));
+                double x, y;
+                uint32_t a = 0;
+                do {
+                    x = (draw(key, SLOT_DISK + 2 * a) - 0.5) * 2;
+                    y = (draw(key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
+                    a++;
+                } while (x * x + y * y >= 1.0);
+                x *= mat->blur; y *= mat->blur;
+                mr.d = vadd(vadd(mr.d, vmul(u, x)), vmul(v, y));
+            }
+            v3 in = ray_color(cx, mr, RT_ZERO, RT_INFINITE, jumpTime, 1, orc_hash2(key, BR_SPECULAR));
+            color = vadd(color, V(mat->mirror[0] * in.x, mat->mirror[1] * in.y, mat->mirror[2] * in.z));
+        }
+        if (mat->type & ORC_MAT_TRANSPARENT) {                           /* :343-373, as :267-303 without emission */
+            ray_t rr;
+            rr.e = p;
+            v3 k = V(1, 1, 1);
+            double cc = 0;
+            v3 r = vreflact(ray.d, rec.normal);
+            int flag = 0;
+            if (vdot(rec.normal, ray.d) > 0) {
+                k.x = exp(-mat->atten[0] * rec.t);
+                k.y = exp(-mat->atten[1] * rec.t);
+                k.z = exp(-mat->atten[2] * rec.t);
+                if (refract_dir(ray.d, vneg(rec.normal), 1 / mat->nr, &rr.d)) {
+                    flag = 1;
+                    ray_t q; q.e = p; q.d = r;
+                    v3 in = ray_color(cx, q, RT_ZERO, RT_INFINITE, jumpTime, 1, orc_hash2(key, BR_REFLECT));
+                    color = vadd(color, V(k.x * in.x, k.y * in.y, k.z * in.z));
+                } else {
+                    cc = vdot(rr.d, rec.normal);
+                }
+            } else {
+                cc = vdot(vneg(ray.d), rec.normal);
+                refract_dir(ray.d, rec.normal, mat->nr, &rr.d);
+            }
+            if (!flag) {
+                double n = mat->nr;
+                double R0 = (n - 1) * (n - 1) / (n + 1) / (n + 1);
+                double R = R0 + (1 - R0) * pow(1 - cc, 5);
+                ray_t q; q.e = p; q.d = r;
+                v3 a = ray_color(cx, q, RT_ZERO, RT_INFINITE, jumpTime, 1, orc_hash2(key, BR_REFLECT));
+                v3 b = ray_color(cx, rr, RT_ZERO, RT_INFINITE, jumpTime, 1, orc_hash2(key, BR_REFRACT));
+                v3 sum = vadd(vmul(a, R), vmul(b, 1 - R));
+                color = vadd(color, V(k.x * sum.x, k.y * sum.y, k.z * sum.z));
+            }
+        }
+        return color;
+    }
     v3 c = mcolor;
     if (jumpTime > cx->rus_jump) {                                       /* :208-212 */
         double pr = (c.x > c.y && c.x > c.z) ? c.x : (c.y > c.z ? c.y : c.z);
@@ -829,8 +914,6 @@ static int check_params(const orc_scene *s, const orc_render_params *p)
     if (p->n <= 0 || p->m <= 0) FAIL("bad jitter table size");
     if (p->sample_begin < 0 || p->sample_end > p->n * p->m || p->sample_begin > p->sample_end) FAIL("bad sample range");
     if (p->max_jump < 0 || p->max_jump > 60) FAIL("bad max_jump");
-    for (uint64_t i = 0; i < s->nmaterials; i++)
-        if (!(s->materials[i].type & ORC_MAT_MONTECARLO)) FAIL("material %d is not a Monte-Carlo material", (int)i);
     return 0;
 }
 

@@ -31,7 +31,7 @@ extern "C" {
 enum { ORC_MAT_NORMAL = 1, ORC_MAT_SPECULAR = 2, ORC_MAT_TRANSPARENT = 4, ORC_MAT_MONTECARLO = 8 };
 /* object kinds -- Surface.h:50-56 plus the new triangle mesh */
 enum { ORC_OBJ_SPHERE = 1, ORC_OBJ_GROUND = 2, ORC_OBJ_WALL_Z = 3, ORC_OBJ_WALL_X = 4, ORC_OBJ_MESH = 5 };
-enum { ORC_LIGHT_SPHERE = 1, ORC_LIGHT_FACE = 2 };
+enum { ORC_LIGHT_SPHERE = 1, ORC_LIGHT_FACE = 2, ORC_LIGHT_POINT = 3 };
 
 #define ORC_MISS 0xFFFFFFFFu
 
@@ -51,6 +51,8 @@ typedef struct {
     double  blur;
     double  atten[3];  /* a_ */
     double  nr;        /* nr_ */
+    double  ambient[3], specular[3], mirror[3];   /* Phong branch only (material.h:59-62) */
+    double  shine;
 } orc_material;
 
 typedef struct {
@@ -63,6 +65,7 @@ typedef struct {
     double  right[3];  /* up ^ normal, NOT normalised (light.cpp:51) */
     double  width, height;
     double  diffuse[3];
+    double  ambient[3], specular[3];              /* Phong branch only (light.h:27-29) */
 } orc_light;
 
 typedef struct {

@@ -162,13 +162,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
 
     for (uint64_t i = 0; i < d->nmaterials; i++) {
         const rt_material &m = d->materials[i];
-        if (!(m.type & RT_MAT_MONTECARLO))
-            return fail("rt_scene_create: material " + std::to_string(i) + " is not a MONTECARLO material (the legacy Phong branch is not on this path)");
         if ((m.type & RT_MAT_TRANSPARENT) && !(m.nr > 0)) return fail("rt_scene_create: transparent material needs nr > 0");
     }
     for (uint64_t i = 0; i < d->nlights; i++) {
         int t = d->lights[i].type;
-        if (t != RT_LIGHT_SPHERE && t != RT_LIGHT_FACE) return fail("rt_scene_create: unknown light type");
+        if (t != RT_LIGHT_SPHERE && t != RT_LIGHT_FACE && t != RT_LIGHT_POINT) return fail("rt_scene_create: unknown light type");
     }
 
     // one octree per mesh, concatenated into scene-wide arrays
@@ -311,7 +309,7 @@ int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double
 int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *prim_id, double *t, uint64_t *counters, void *stream)
 {
     if (!s || !cam) return fail("rt_trace_primary: null argument");
-    if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail("rt_trace_primary: bad image size");
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || (uint64_t)w * (uint64_t)h >= 0xFFFF0000ull) return fail("rt_trace_primary: bad image size");
     if (!prim_id) return fail("rt_trace_primary: null buffer");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 3, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
@@ -363,9 +361,21 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
                                                                      // busy (20 and more rays per lane) and cost only stack memory
     if (target > total_items * max_push) target = total_items * max_push;
     if (target < RT_BLOCK) target = RT_BLOCK;
-    const uint64_t cap = target * (max_push + 3);
+    uint64_t cap = target * (max_push + 3);
+    while (cap >= 0xFFFFFFF0ull && target > (1u << 20)) { target >>= 1; cap = target * (max_push + 3); }
     if (cap >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
-    if (int rc = ensure_stacks(s, cap, st)) return rc;
+    // the stacks are sized for a large part (4 x 9.4 GB for two pushes per ray); on a device with
+    // less free memory fall back to smaller rounds rather than fail
+    for (;;) {
+        const int rc = ensure_stacks(s, cap, st);
+        if (rc == 0) break;
+        if (target <= (1u << 20)) return rc;
+        (void)hipGetLastError();
+        for (int c = 0; c < 2; c++)
+            for (int k = 0; k < 2; k++)
+                if (s->stack_mem[c][k]) { (void)hipFree(s->stack_mem[c][k]); s->stack_mem[c][k] = nullptr; s->stack[c][k].cap = 0; }
+        target >>= 1; cap = target * (max_push + 3);
+    }
 
     uint64_t count[2][2] = {{0, 0}, {0, 0}};      // [class][side]
     int cur[2] = {0, 0};                          // side that is the class's source

@@ -860,6 +860,11 @@ __device__ inline V3 first_intersection_sphere(V3 re, V3 rd, V3 center, double r
 __device__ inline V3 light_sample(const rt_light &l, V3 ppos, double ru, double rv, V3 &normal, double &p)
 {
     V3 pos_ = ld3(l.pos);
+    if (l.type == RT_LIGHT_POINT) {                        // Light::getPosition, light.cpp:37-41: the normal stays (0,0,0)
+        p = 1;
+        normal = mk(0, 0, 0);
+        return pos_;
+    }
     if (l.type == RT_LIGHT_FACE) {
         V3 pos = pos_ + ((ld3(l.right) * (ru - 0.5)) * l.width + (ld3(l.up) * (rv - 0.5)) * l.height);
         p = 1.0 / l.width / l.height;
@@ -1095,16 +1100,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     if (shade) normal = hit_normal(S, h, p);
     const V3 emission = ld3(mat.emission), mcolor = ld3(mat.color);
     const double Ed = (double)E;
+    // mc: the Monte-Carlo branch (scene.cpp:205-304); otherwise the Phong / Whitted branch
+    // (scene.cpp:305-375): no roulette, no emission, ambient + shadowed diffuse / specular terms
+    // per light instead of the diffuse bounce, the mirror colour instead of getColor()
+    const bool mc = (mtype & RT_MAT_MONTECARLO) != 0;
     V3 cc = mcolor;
     bool alive = shade;
-    if (shade && jt > A.rus_jump) {                                          // Russian roulette, scene.cpp:208-212
+    if (shade && mc && jt > A.rus_jump) {                                    // Russian roulette, scene.cpp:208-212
         double pr = (cc.x > cc.y && cc.x > cc.z) ? cc.x : (cc.y > cc.z ? cc.y : cc.z);
         if (draw(key, SLOT_RR) < pr) cc = cc * (1 / pr);
         else { sum = sum + had(W, emission * Ed); alive = false; }
     }
 
     // ---- diffuse lobe, scene.cpp:213-248
-    const bool lobeN = alive && (mtype & RT_MAT_NORMAL);
+    const bool lobeN = alive && mc && (mtype & RT_MAT_NORMAL);
+    const bool phongN = alive && !mc && (mtype & RT_MAT_NORMAL);
     V3 w = normal, dn = mk(0, 0, 0), wn = normal;
     if (lobeN) {
         double r1 = RT_PI * 2 * draw(key, SLOT_DIFF1);
@@ -1143,6 +1153,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
                     want = true;
                 }
             }
+        } else if (phongN) {                                                 // scene.cpp:307-322
+            const rt_light &L = S.lights[li];
+            sum = sum + had(W, had(ld3(L.ambient), ld3(mat.ambient)));
+            // light->getPosition() without a hit record: the point itself, a jittered point of a
+            // FaceLight; a SphereLight (which would dereference the null record, light.cpp:143) is
+            // taken at its centre
+            V3 lightpos = ld3(L.pos);
+            if (L.type == RT_LIGHT_FACE) {
+                double lu, lv;
+                jitter_pair(A.seed, pix, 1u + (uint32_t)li, k, tab_n, tab_m, lu, lv);
+                V3 nl; double pr;
+                lightpos = light_sample(L, p, lu, lv, nl, pr);
+            }
+            ldir = norm(lightpos - p);
+            dist = len(lightpos - p);
+            double kd = dot(normal, ldir);
+            if (!(0.0 < kd)) kd = 0.0;                                       // max(0.0, n.d)
+            const double ks = pow(dot(norm(ldir - rd), normal), mat.shine);
+            contrib = had(W, had(mcolor, ld3(L.diffuse) * kd) + had(ld3(mat.specular), ld3(L.specular) * ks));
+            want = true;                                                     // the shadow test is made whatever it will deliver
         }
         if (li == 0) { want0 = want; ldir0 = ldir; contrib0 = contrib; dist0 = dist; continue; }
         const int cls = want ? ray_class(S, p, ldir, dist - RT_ZERO) : 0;
@@ -1172,10 +1202,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             x *= mat.blur; y *= mat.blur;
             md = (md + u * x) + v * y;
         }
-        sum = sum + had(W, emission * Ed);
+        if (mc) sum = sum + had(W, emission * Ed);
     }
+    const V3 mweight = mc ? mcolor : ld3(mat.mirror);                        // scene.cpp:265 / :341
 
-    // ---- dielectric lobe, scene.cpp:267-303
+    // ---- dielectric lobe, scene.cpp:267-303 (and :343-373)
     const bool lobeT = alive && (mtype & RT_MAT_TRANSPARENT);
     V3 kk = mk(1, 1, 1), r = mk(0, 0, 0), rfr = mk(0, 0, 0);
     double R = 0;
@@ -1187,7 +1218,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             kk.x = exp(-mat.atten[0] * ht);
             kk.y = exp(-mat.atten[1] * ht);
             kk.z = exp(-mat.atten[2] * ht);
-            if (refract_dir(rd, -normal, 1 / mat.nr, rfr)) { tir = true; sum = sum + had(W, emission * Ed); }
+            if (refract_dir(rd, -normal, 1 / mat.nr, rfr)) { tir = true; if (mc) sum = sum + had(W, emission * Ed); }
             else cosv = dot(rfr, normal);
         } else {
             cosv = dot(-rd, normal);
@@ -1223,7 +1254,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         slot = take_slot(cur, a1, b1, k1);
         if (want0) ray_store(D.q[k1], slot, p, ldir0, dist0 - RT_ZERO, contrib0, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
         slot = take_slot(cur, a2, b2, k2);
-        if (lobeS) ray_store(D.q[k2], slot, p, md, RT_INFINITE, had(W, mcolor), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        if (lobeS) ray_store(D.q[k2], slot, p, md, RT_INFINITE, had(W, mweight), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
         // reflected ray: weight k (total internal reflection) or k*R
         slot = take_slot(cur, a3, b3, k3);
         if (lobeT) ray_store(D.q[k3], slot, p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));

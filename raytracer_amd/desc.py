@@ -17,7 +17,7 @@ import numpy as np
 MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MAT_MONTECARLO = 1, 2, 4, 8
 # object kinds -- Surface.h:50-56 (+ the triangle mesh this build adds)
 OBJ_SPHERE, OBJ_GROUND, OBJ_WALL_Z, OBJ_WALL_X, OBJ_MESH = 1, 2, 3, 4, 5
-LIGHT_SPHERE, LIGHT_FACE = 1, 2
+LIGHT_SPHERE, LIGHT_FACE, LIGHT_POINT = 1, 2, 3
 MISS = 0xFFFFFFFF
 
 INFINITE = 1e10   # definitions.h:5
@@ -28,13 +28,15 @@ OBJECT_DT = np.dtype([("type", "<i4"), ("material", "<i4"), ("mesh", "<i4"), ("r
                       ("p", "<f8", (4,))], align=True)
 MATERIAL_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("emission", "<f8", (3,)),
                         ("color", "<f8", (3,)), ("blur", "<f8"), ("atten", "<f8", (3,)),
-                        ("nr", "<f8")], align=True)
+                        ("nr", "<f8"), ("ambient", "<f8", (3,)), ("specular", "<f8", (3,)),
+                        ("mirror", "<f8", (3,)), ("shine", "<f8")], align=True)
 LIGHT_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("pos", "<f8", (3,)), ("radius", "<f8"),
                      ("normal", "<f8", (3,)), ("up", "<f8", (3,)), ("right", "<f8", (3,)),
-                     ("width", "<f8"), ("height", "<f8"), ("diffuse", "<f8", (3,))], align=True)
+                     ("width", "<f8"), ("height", "<f8"), ("diffuse", "<f8", (3,)),
+                     ("ambient", "<f8", (3,)), ("specular", "<f8", (3,))], align=True)
 RAY_DT = np.dtype([("e", "<f8", (3,)), ("d", "<f8", (3,))], align=True)
 
-assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 96 and LIGHT_DT.itemsize == 152
+assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 176 and LIGHT_DT.itemsize == 200
 
 
 class MeshC(C.Structure):

@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-from .desc import (LIGHT_DT, LIGHT_FACE, LIGHT_SPHERE, MAT_MONTECARLO, MAT_NORMAL, MAT_SPECULAR,
+from .desc import (LIGHT_DT, LIGHT_FACE, LIGHT_POINT, LIGHT_SPHERE, MAT_MONTECARLO, MAT_NORMAL, MAT_SPECULAR,
                    MAT_TRANSPARENT, MATERIAL_DT, OBJ_GROUND, OBJ_MESH, OBJ_SPHERE, OBJ_WALL_X, OBJ_WALL_Z,
                    OBJECT_DT, SceneDesc)
 
@@ -21,6 +21,31 @@ def material(kind, emission=(0, 0, 0), color=(0, 0, 0), blur=0.0, atten=(0, 0, 0
     m["type"] = int(kind) | MAT_MONTECARLO
     m["emission"], m["color"], m["blur"], m["atten"], m["nr"] = emission, color, blur, atten, nr
     return m
+
+
+def phong_material(ambient=(0, 0, 0), diffuse=(0, 0, 0), specular=(0, 0, 0), shine=1.0, mirror=None, blur=0.0):
+    """Material(amb, dif, spe, shi) / Material(amb, dif, spe, mir, shi) -- material.cpp:2-12: the
+    materials of the Phong / Whitted branch (no MONTECARLO flag)."""
+    m = np.zeros((), MATERIAL_DT)
+    m["type"] = MAT_NORMAL if mirror is None else (MAT_NORMAL | MAT_SPECULAR)
+    m["ambient"], m["color"], m["specular"], m["shine"], m["blur"], m["nr"] = ambient, diffuse, specular, shine, blur, 1.0
+    if mirror is not None:
+        m["mirror"] = mirror
+    return m
+
+
+def glass_material(atten, nr):
+    """Material(a, nr) -- material.cpp:19-23: TRANSPARENT, shaded by the Whitted branch."""
+    m = np.zeros((), MATERIAL_DT)
+    m["type"], m["atten"], m["nr"] = MAT_TRANSPARENT, atten, nr
+    return m
+
+
+def point_light(pos, ambient, diffuse, specular):
+    """Light(pos, ambient, diffuse, specular) -- light.cpp:8-11."""
+    l = np.zeros((), LIGHT_DT)
+    l["type"], l["pos"], l["ambient"], l["diffuse"], l["specular"] = LIGHT_POINT, pos, ambient, diffuse, specular
+    return l
 
 
 def sphere(center, radius, mat):
@@ -50,7 +75,7 @@ def sphere_light(pos, radius, emission):
     return l
 
 
-def face_light(pos, normal, up, width, height, diffuse):
+def face_light(pos, normal, up, width, height, diffuse, ambient=(0, 0, 0), specular=(0, 0, 0)):
     """FaceLight(pos, normal, up, width, height, ...) -- light.cpp:50-56: right = up ^ normal,
     normal normalised as v * (1/|v|)."""
     l = np.zeros((), LIGHT_DT)
@@ -59,7 +84,7 @@ def face_light(pos, normal, up, width, height, diffuse):
     right = np.array([u[1] * n[2] - n[1] * u[2], u[2] * n[0] - u[0] * n[2], u[0] * n[1] - n[0] * u[1]])
     inv = 1 / math.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
     l["type"], l["pos"], l["normal"], l["up"], l["right"] = LIGHT_FACE, pos, n * inv, u, right
-    l["width"], l["height"], l["diffuse"] = width, height, diffuse
+    l["width"], l["height"], l["diffuse"], l["ambient"], l["specular"] = width, height, diffuse, ambient, specular
     return l
 
 
@@ -299,6 +324,29 @@ def three_sphere_scene(light="sphere"):
     desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [],
                      background=(0.05, 0.07, 0.1))
     cam = dict(look_from=(0, 2.5, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=40.0, aspect=4 / 3)
+    return desc, cam
+
+
+def phong_scene(light="point"):
+    """Scene for the Phong / Whitted branch of Scene::rayColor (scene.cpp:305-375): a Phong
+    sphere, a Phong + mirror sphere (blurred), a glass sphere (Material(a, nr)), a small Phong
+    mesh, Phong floor and walls, lit by two point Lights or by a point Light and a FaceLight."""
+    mats = [phong_material((.10, .04, .04), (.70, .25, .25), (.5, .5, .5), 24.0),
+            phong_material((.02, .02, .02), (.10, .10, .12), (.6, .6, .6), 60.0, mirror=(.75, .75, .8), blur=0.03),
+            glass_material((.02, .03, .05), 1.5),
+            phong_material((.05, .06, .05), (.45, .55, .40), (.2, .2, .2), 8.0),
+            phong_material((.05, .05, .06), (.50, .50, .60), (.1, .1, .1), 4.0, mirror=(.25, .25, .25))]
+    objs = [sphere((0, 1, 0), 1.0, 0), sphere((2.3, 1, 0.4), 1.0, 1), sphere((-2.3, 1, 0.8), 1.0, 2),
+            mesh_object(0, 3), plane(OBJ_GROUND, 0.0, 4), plane(OBJ_WALL_Z, -4.0, 3), plane(OBJ_WALL_X, -6.0, 3)]
+    lights = [point_light((4, 7, 5), (.5, .5, .5), (.9, .9, .8), (1, 1, 1))]
+    if light == "point":
+        lights.append(point_light((-5, 4, 6), (.2, .2, .3), (.3, .3, .5), (.4, .4, .6)))
+    else:
+        lights.append(face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, (.5, .5, .6), ambient=(.2, .2, .2), specular=(.5, .5, .5)))
+    body = blob((0.3, 2.9, 0.2), 0.7, 14, 15, seed=5)
+    desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [body],
+                     background=(0.05, 0.07, 0.1))
+    cam = dict(look_from=(0.5, 2.8, 9), look_at=(0, 1.2, 0), vup=(0, 1, 0), vfov=42.0, aspect=4 / 3)
     return desc, cam
 
 

@@ -92,10 +92,13 @@ def test_bmp_header_and_payload(tmp_path):
 def test_invalid_scenes_are_rejected_before_any_device_work():
     L = hip.lib()
     good, _ = scenes.three_sphere_scene()
-    # legacy (non Monte-Carlo) material: not on this path -> error, not a silent fallback
+    bad = D.SceneDesc(good.objects, good.materials, good.lights.copy(), [])
+    bad.lights["type"][0] = 9
+    with pytest.raises(hip.RtError, match="light type"):
+        hip.HipScene(bad)
     bad = D.SceneDesc(good.objects, good.materials.copy(), good.lights, [])
-    bad.materials["type"][0] = D.MAT_NORMAL
-    with pytest.raises(hip.RtError, match="MONTECARLO"):
+    bad.materials["type"][2] = D.MAT_TRANSPARENT; bad.materials["nr"][2] = 0.0
+    with pytest.raises(hip.RtError, match="nr"):
         hip.HipScene(bad)
     bad = D.SceneDesc(good.objects.copy(), good.materials, good.lights, [])
     bad.objects["material"][1] = 99

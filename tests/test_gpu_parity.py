@@ -348,6 +348,29 @@ def test_scaled_scene_bit_exact(scale):
     assert (p1 != MISS).mean() > 0.2
 
 
+@pytest.mark.parametrize("light", ["point", "face"])
+def test_phong_whitted_branch(light):
+    """Materials without the MONTECARLO flag: ambient / diffuse / specular per light with shadow
+    rays, Whitted mirror (blurred) and glass, point Lights and a FaceLight (scene.cpp:305-375)."""
+    desc, cam = scenes.phong_scene(light)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    W, H = 96, 72
+    rays = _camera_rays(c, W, H)
+    prm = render_params(W, H, 1, seed=21, max_jump=10)
+    c1, k1 = so.ray_color(rays, prm)
+    c2, k2 = sg.ray_color(rays, prm)
+    assert np.array_equal(k1, k2)                         # identical ray trees
+    r = _rel(c1, c2).max(axis=1)
+    assert (r > PATH_RTOL).mean() <= 1e-4, r.max()
+    assert c1.mean() > 0.1
+    prm = render_params(W, H, 2, seed=22, max_jump=8)
+    i1, k1 = so.render(c, prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2) and np.sqrt((((i1 - i2) / 4) ** 2).mean()) <= RMSE_TOL
+    assert (_rel(i1, i2) > PATH_RTOL).mean() <= 1e-4
+
+
 def test_profile_counters_are_consistent():
     desc, cam = scenes.bunny_cornell_scene(nu=24, nv=25)
     sg = hip.HipScene(desc)

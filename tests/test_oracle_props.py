@@ -142,6 +142,45 @@ def test_nee_single_face_light_closed_form():
     assert cnt[0] == 2                        # camera ray + shadow ray (bounce is cut by max_jump)
 
 
+def test_phong_branch_closed_form():
+    """Phong / Whitted branch (scene.cpp:305-375): a ground plane seen straight down, one point
+    Light: ambient + diffuse * max(0, n.l) + specular * ((l - d)^ . n)^shine; a blocker between
+    the point and the light leaves the ambient term only."""
+    amb, dif, spe, shi = np.array([.1, .2, .3]), np.array([.6, .5, .4]), np.array([.9, .8, .7]), 5.0
+    la, ld_, ls = np.array([.5, .5, .5]), np.array([2., 3., 4.]), np.array([1., .5, .25])
+    mats = scenes._stack([scenes.phong_material(amb, dif, spe, shi), scenes.phong_material()], MATERIAL_DT)
+    light = scenes.point_light((3, 4, 0), la, ld_, ls)
+    r = np.zeros(1, RAY_DT); r["e"][0] = (0, 1, 0); r["d"][0] = (0, -1, 0)
+    prm = render_params(1, 1, 1, seed=1)
+    s = orc.OracleScene(SceneDesc(scenes._stack([scenes.plane(2, 0.0, 0)], OBJECT_DT), mats, scenes._stack([light], LIGHT_DT), [],
+                                  background=(0, 0, 0)))
+    out, cnt = s.ray_color(r, prm)
+    l = np.array([3, 4, 0]) / 5.0
+    n, d = np.array([0, 1, 0.]), np.array([0, -1, 0.])
+    hv = (l - d) / np.linalg.norm(l - d)
+    expect = la * amb + dif * ld_ * max(0.0, n @ l) + spe * ls * (hv @ n) ** shi
+    assert np.allclose(out[0], expect, rtol=1e-14)
+    assert cnt[0] == 2                        # the ray and one shadow ray
+    blocked = scenes._stack([scenes.plane(2, 0.0, 0), scenes.sphere((1.5, 2, 0), 0.5, 1)], OBJECT_DT)
+    s = orc.OracleScene(SceneDesc(blocked, mats, scenes._stack([light], LIGHT_DT), [], background=(0, 0, 0)))
+    out, _ = s.ray_color(r, prm)
+    assert np.allclose(out[0], la * amb, rtol=1e-15)
+
+
+def test_phong_mirror_and_glass_weights():
+    """Whitted mirror: getMirror() x the reflected radiance, nothing else (scene.cpp:341); glass
+    (Material(a, nr)) without absorption under a uniform sky returns the sky (scene.cpp:343-373)."""
+    B, mir = np.array([.3, .6, .9]), np.array([.5, .25, .125])
+    mat = scenes.phong_material(mirror=mir)
+    mat["type"] = MAT_SPECULAR                       # mirror lobe only
+    s = orc.OracleScene(_one_sphere(mat, background=B))
+    out, _ = s.ray_color(_rays_at_sphere(50, 2), render_params(1, 1, 1, seed=5))
+    assert np.allclose(out, np.tile(mir * B, (50, 1)), rtol=1e-15)
+    s = orc.OracleScene(_one_sphere(scenes.glass_material((0, 0, 0), 1.5), background=B))
+    out, _ = s.ray_color(_rays_at_sphere(40, 3), render_params(1, 1, 1, seed=5, max_jump=10))
+    assert np.allclose(out, np.tile(B, (40, 1)), rtol=1e-12)
+
+
 def test_sample_slices_add_up():
     desc, cam = scenes.three_sphere_scene("sphere")
     s = orc.OracleScene(desc)
