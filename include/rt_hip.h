@@ -101,6 +101,10 @@ typedef struct {
     double llc[3];   /* leftLowerCorner */
     double u[3], v[3];
     double width, height;
+    double look_at[3];  /* lookAt_ (ChangeFovCamera::timeChanged needs it, camera.cpp:88-94) */
+    double aperture;    /* DepthCamera's lens radius factor (camera.cpp:50-72); 0 = pinhole Camera.
+                           Set by the caller after rt_camera_init; used by rt_render only
+                           (rt_trace_primary always takes the ray through the lens centre). */
 } rt_camera;
 
 /* Scene's private sampler / integrator constants, made settable -- scene.h:52-54 */
@@ -135,6 +139,15 @@ int rt_scene_octree_stats(const rt_scene *scene, int mesh, uint64_t out[6]);
 /* Camera::Camera -> init, camera.cpp:5-8,37-48 (host arithmetic) */
 int rt_camera_init(const double look_from[3], const double look_at[3], const double vup[3],
                    double vfov, double aspect, rt_camera *out);
+/* ChangeFovCamera::timeChanged(time), camera.cpp:88-94: the film of `origin` scaled by
+ * sqrt(sin(2 pi time) * 1.5 + 1.6) + 0.3 around lookAt (host arithmetic; out may not alias origin) */
+int rt_camera_change_fov(const rt_camera *origin, double time, rt_camera *out);
+/* MovableFaceLight (light.cpp:87-107) at `time`: `origin` moved on its circle around the y axis */
+int rt_light_move_face(const rt_light *origin, double time, rt_light *out);
+/* Replaces light `index` of an uploaded scene (animated lights: RTObject::setTime cascade,
+ * RTObject.h:110-117) without rebuilding anything else.  The light's geometry, if it has any
+ * (SphereLight), is an object of the scene and does not move with it. */
+int rt_scene_set_light(rt_scene *scene, uint64_t index, const rt_light *light, void *stream);
 
 /* Closest hit for a batch of rays = group_->calHit(ray, t0, t1, &rec) (scene.cpp:202,
  * Surface.cpp:160-181, octree.cpp:285-376).  prim_id[i] = global primitive id (objects in

@@ -180,9 +180,24 @@ public:
         const double f[3] = {lookFrom.x_, lookFrom.y_, lookFrom.z_}, a[3] = {lookAt.x_, lookAt.y_, lookAt.z_}, u[3] = {vup.x_, vup.y_, vup.z_};
         rt_camera_init(f, a, u, vfov, aspect, &rec_);
     }
+    virtual ~Camera() = default;
+    virtual void setTime(double) {}                                          // RTObject.h:110-117
     const rt_camera &record() const { return rec_; }
-private:
+protected:
     rt_camera rec_;
+};
+class ChangeFovCamera : public Camera {                                      // camera.cpp:74-94
+public:
+    ChangeFovCamera(Vec3 lookFrom, Vec3 lookAt, Vec3 vup, double vfov, double aspect)
+        : Camera(lookFrom, lookAt, vup, vfov, aspect), origin_(rec_) {}
+    void setTime(double time) override { rt_camera_change_fov(&origin_, time, &rec_); }
+private:
+    rt_camera origin_;
+};
+class DepthCamera : public Camera {                                          // camera.cpp:50-72
+public:
+    DepthCamera(Vec3 lookFrom, Vec3 lookAt, Vec3 vup, double vfov, double aspect, double aperture)
+        : Camera(lookFrom, lookAt, vup, vfov, aspect) { rec_.aperture = aperture; }
 };
 
 class Light {                                                                // light.h:8-30
@@ -196,6 +211,7 @@ public:
     }
     virtual ~Light() = default;
     virtual std::shared_ptr<Drawable> getGeometry() { return nullptr; }
+    virtual bool setTime(double) { return false; }                           // true if the record changed
     const rt_light &record() const { return rec_; }
 protected:
     void set_colors(const Color &a, const Color &d, const Color &sp)
@@ -235,6 +251,15 @@ public:
     }
 };
 
+class MovableFaceLight : public FaceLight {                                 // light.cpp:87-107
+public:
+    MovableFaceLight(Vec3 pos, Vec3 normal, Vec3 up, double width, double height, Color ambient, Color diffuse, Color specular)
+        : FaceLight(pos, normal, up, width, height, ambient, diffuse, specular), origin_(rec_) {}
+    bool setTime(double time) override { return rt_light_move_face(&origin_, time, &rec_) == 0; }
+private:
+    rt_light origin_;
+};
+
 class Scene {                                                                // scene.h:8-56
 public:
     Scene() = default;
@@ -260,6 +285,16 @@ public:
     void setSeed(uint64_t s) { seed_ = s; }
     void setFaceForward(bool on) { faceForward_ = on; }
     void setOctree(int maxSize, int maxDepth) { octMax_ = maxSize; octDepth_ = maxDepth; dirty_ = true; }
+    // RTObject::setTime cascade (RTObject.h:110-117, main.cpp:85): the camera and the lights follow
+    // the clock; a moved light is patched into the uploaded scene, nothing is rebuilt.
+    int setTime(double time)
+    {
+        if (camera_) camera_->setTime(time);
+        for (size_t i = 0; i < lights_.size(); i++)
+            if (lights_[i]->setTime(time) && handle_ && !dirty_)
+                if (rt_scene_set_light(handle_, i, &lights_[i]->record(), nullptr)) return -1;
+        return 0;
+    }
 
     // Scene::run() / runParallelly(threadNum), scene.cpp:95-172: the whole frame, on the GPU.
     int run() { return runParallelly(0); }

@@ -617,6 +617,45 @@ void orc_camera_init(const double from[3], const double at[3], const double vup[
     v3 llc = vsub(vsub(la, vmul(v, height / 2)), vmul(u, width / 2));
     v3st(out->e, lf); v3st(out->llc, llc); v3st(out->u, u); v3st(out->v, v);
     out->width = width; out->height = height;
+    v3st(out->look_at, la);
+    out->aperture = 0;
+}
+/* ChangeFovCamera::timeChanged, camera.cpp:88-94 */
+void orc_camera_change_fov(const orc_camera *origin, double time, orc_camera *out)
+{
+    *out = *origin;
+    double scale = sqrt(sin(time * 2 * 3.1415926) * 1.5 + 1.6) + 0.3;
+    out->height = origin->height * scale;
+    out->width = origin->width * scale;
+    v3 llc = vsub(vsub(v3p(origin->look_at), vmul(v3p(origin->v), out->height / 2)), vmul(v3p(origin->u), out->width / 2));
+    v3st(out->llc, llc);
+}
+/* MovableFaceLight, light.cpp:87-107: the light circles the y axis at its original distance */
+void orc_light_move_face(const orc_light *origin, double time, orc_light *out)
+{
+    *out = *origin;
+    double radius = sqrt(origin->pos[0] * origin->pos[0] + origin->pos[2] * origin->pos[2]);
+    out->pos[0] = sin(time * 2 * 3.1415926) * radius;
+    out->pos[2] = cos(time * 2 * 3.1415926) * radius;
+}
+/* DepthCamera::getRay, camera.cpp:62-72: the origin moves on the lens disk (randFromDisk,
+ * algorithms.h:30-35, drawn from the sample's own key), the film point stays */
+#define KEY_LENS 0x4c454e53ULL
+static ray_t camera_ray_lens(const orc_camera *c, float s, float t, uint64_t root_key)
+{
+    ray_t r;
+    uint64_t key = orc_hash2(root_key, KEY_LENS);
+    double x, y;
+    uint32_t a = 0;
+    do {
+        x = (draw(key, SLOT_DISK + 2 * a) - 0.5) * 2;
+        y = (draw(key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
+        a++;
+    } while (x * x + y * y >= 1.0);
+    r.e = vadd(vadd(v3p(c->e), vmul(v3p(c->u), x * c->aperture)), vmul(v3p(c->v), y * c->aperture));
+    v3 lookat = vadd(vadd(v3p(c->llc), vmul(vmul(v3p(c->u), s), c->width)), vmul(vmul(v3p(c->v), t), c->height));
+    r.d = vnorm(vsub(lookat, r.e));
+    return r;
 }
 static ray_t camera_ray(const orc_camera *c, float s, float t)
 {
@@ -945,9 +984,11 @@ static void render_pixel(const orc_scene *s, const orc_camera *cam, const orc_re
         orc_jitter_pair(p->seed, pix, 0, (uint32_t)k, (uint32_t)p->n, (uint32_t)p->m, pr);
         for (uint64_t li = 0; li < s->nlights; li++)
             orc_jitter_pair(p->seed, pix, 1 + (uint32_t)li, (uint32_t)k, (uint32_t)p->n, (uint32_t)p->m, uv + 2 * li);
-        ray_t ray = camera_ray(cam, (float)((pr[0] + x * 1.0) / p->width), (float)((pr[1] + y * 1.0) / p->height));
+        const uint64_t root = orc_path_root_key(p->seed, pix, (uint32_t)k);
+        const float fs = (float)((pr[0] + x * 1.0) / p->width), ft = (float)((pr[1] + y * 1.0) / p->height);
+        ray_t ray = cam->aperture != 0 ? camera_ray_lens(cam, fs, ft, root) : camera_ray(cam, fs, ft);
         pctx cx = { s, p->max_jump, p->rus_jump, p->face_forward, uv, c };
-        color = vadd(color, ray_color(&cx, ray, 0, RT_INFINITE, 0, 1, orc_path_root_key(p->seed, pix, (uint32_t)k)));
+        color = vadd(color, ray_color(&cx, ray, 0, RT_INFINITE, 0, 1, root));
     }
     out[0] += color.x; out[1] += color.y; out[2] += color.z;
 }

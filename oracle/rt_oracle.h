@@ -91,6 +91,8 @@ typedef struct {
     double llc[3];   /* leftLowerCorner */
     double u[3], v[3];
     double width, height;
+    double look_at[3];   /* lookAt_, used by ChangeFovCamera::timeChanged (camera.cpp:88-94) */
+    double aperture;     /* DepthCamera (camera.cpp:50-72); 0 = the plain pinhole Camera */
 } orc_camera;
 
 typedef struct {
@@ -120,6 +122,10 @@ void orc_camera_init(const double from[3], const double at[3], const double vup[
                      double vfov, double aspect, orc_camera *out);
 /* Camera::getRay, camera.cpp:24-31 (s,t rounded to float as in the reference signature) */
 void orc_camera_get_ray(const orc_camera *c, double s, double t, orc_ray *out);
+/* ChangeFovCamera::timeChanged (camera.cpp:88-94) applied to `origin`; MovableFaceLight::getPosition's
+ * move of the light (light.cpp:101-107) applied to `origin` */
+void orc_camera_change_fov(const orc_camera *origin, double time, orc_camera *out);
+void orc_light_move_face(const orc_light *origin, double time, orc_light *out);
 
 /* closest hit through Group::hit; prim_id = global primitive id or ORC_MISS.
  * counters (nullable) += {group rays, inner-node visits, leaf visits, primitive tests} */

@@ -106,6 +106,44 @@ int rt_camera_init(const double from[3], const double at[3], const double vup[3]
     }
     out->width = width;
     out->height = height;
+    for (int k = 0; k < 3; k++) out->look_at[k] = at[k];
+    out->aperture = 0;
+    return 0;
+}
+
+int rt_camera_change_fov(const rt_camera *origin, double time, rt_camera *out)
+{
+    if (!origin || !out || origin == out) return fail("rt_camera_change_fov: bad argument");
+    *out = *origin;
+    const double scale = std::sqrt(std::sin(time * 2 * 3.1415926) * 1.5 + 1.6) + 0.3;     // camera.cpp:90
+    out->height = origin->height * scale;
+    out->width = origin->width * scale;
+    for (int k = 0; k < 3; k++)
+        out->llc[k] = (origin->look_at[k] - origin->v[k] * (out->height / 2)) - origin->u[k] * (out->width / 2);
+    return 0;
+}
+
+int rt_light_move_face(const rt_light *origin, double time, rt_light *out)
+{
+    if (!origin || !out) return fail("rt_light_move_face: null argument");
+    const double radius = std::sqrt(origin->pos[0] * origin->pos[0] + origin->pos[2] * origin->pos[2]);   // light.cpp:90
+    rt_light l = *origin;
+    l.pos[0] = std::sin(time * 2 * 3.1415926) * radius;                                   // light.cpp:104-105
+    l.pos[2] = std::cos(time * 2 * 3.1415926) * radius;
+    *out = l;
+    return 0;
+}
+
+int rt_scene_set_light(rt_scene *s, uint64_t index, const rt_light *light, void *stream)
+{
+    if (!s || !light) return fail("rt_scene_set_light: null argument");
+    if (index >= (uint64_t)s->nlights) return fail("rt_scene_set_light: light index out of range");
+    if (light->type != RT_LIGHT_SPHERE && light->type != RT_LIGHT_FACE && light->type != RT_LIGHT_POINT)
+        return fail("rt_scene_set_light: unknown light type");
+    HIP_TRY(hipSetDevice(s->device));
+    // the record is copied from pageable memory: synchronous with respect to the host buffer
+    HIP_TRY(hipMemcpyAsync((void *)(s->dev.lights + index), light, sizeof(rt_light), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

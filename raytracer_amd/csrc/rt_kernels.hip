@@ -759,6 +759,24 @@ __device__ __forceinline__ void camera_ray(const rt_camera &c, float s, float t,
     d = norm(lookat - e);
 }
 
+// DepthCamera::getRay, camera.cpp:62-72: the origin moves on the lens disk (randFromDisk,
+// algorithms.h:30-35, drawn from the sample's own key), the film point stays
+#define KEY_LENS 0x4c454e53ULL
+__device__ inline void camera_ray_lens(const rt_camera &c, float s, float t, uint64_t root_key, V3 &e, V3 &d)
+{
+    const uint64_t key = hash2(root_key, KEY_LENS);
+    double x, y;
+    uint32_t a = 0;
+    do {
+        x = (draw(key, SLOT_DISK + 2 * a) - 0.5) * 2;
+        y = (draw(key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
+        a++;
+    } while (x * x + y * y >= 1.0);
+    e = (ld3(c.e) + ld3(c.u) * (x * c.aperture)) + ld3(c.v) * (y * c.aperture);
+    V3 lookat = ld3(c.llc) + (ld3(c.u) * (double)s) * c.width + (ld3(c.v) * (double)t) * c.height;
+    d = norm(lookat - e);
+}
+
 __device__ inline void flush_counters(uint64_t *counters, const Counters &c)
 {
     if (!counters) return;
@@ -1003,7 +1021,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(DevScene S, WaveArgs A, R
         pix = (uint32_t)y * (uint32_t)A.width + (uint32_t)x;
         double jx, jy;                                          // Scene::run, scene.cpp:105-108
         jitter_pair(A.seed, pix, 0, k, (uint32_t)A.n, (uint32_t)A.m, jx, jy);
-        camera_ray(A.cam, (float)((jx + x * 1.0) / A.width), (float)((jy + y * 1.0) / A.height), e, d);
+        const float fs = (float)((jx + x * 1.0) / A.width), ft = (float)((jy + y * 1.0) / A.height);
+        if (A.cam.aperture != 0) camera_ray_lens(A.cam, fs, ft, path_root_key(A.seed, pix, k), e, d);
+        else camera_ray(A.cam, fs, ft, e, d);
         t1 = A.t1;
     }
     const int cls = live ? ray_class(S, e, d, t1) : 0;

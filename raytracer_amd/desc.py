@@ -56,7 +56,8 @@ class SceneDescC(C.Structure):
 
 class CameraC(C.Structure):
     _fields_ = [("e", C.c_double * 3), ("llc", C.c_double * 3), ("u", C.c_double * 3),
-                ("v", C.c_double * 3), ("width", C.c_double), ("height", C.c_double)]
+                ("v", C.c_double * 3), ("width", C.c_double), ("height", C.c_double),
+                ("look_at", C.c_double * 3), ("aperture", C.c_double)]
 
 
 class RenderParamsC(C.Structure):

@@ -21,6 +21,7 @@ EXPORTS = (
     "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
+    "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
 )
 
 _lib = None
@@ -61,6 +62,9 @@ def lib():
     L.rt_resolve_bgr8.argtypes = [_vp, _int, _int, _int, _vp, _vp]
     L.rt_resolve_bgr8_host.argtypes = [_vp, _int, _int, _int, _vp]
     L.rt_save_bmp.argtypes = [_vp, _int, _int, C.c_char_p]
+    L.rt_camera_change_fov.argtypes = [C.POINTER(CameraC), _dbl, C.POINTER(CameraC)]
+    L.rt_light_move_face.argtypes = [_vp, _dbl, _vp]
+    L.rt_scene_set_light.argtypes = [_vp, _u64, _vp, _vp]
     _lib = L
     return L
 
@@ -99,6 +103,22 @@ def camera_init(look_from, look_at, vup, vfov, aspect):
     _chk(lib().rt_camera_init(_d3(look_from), _d3(look_at), _d3(vup), float(vfov), float(aspect), C.byref(cam)),
          "rt_camera_init")
     return cam
+
+
+def camera_change_fov(origin, time):
+    """ChangeFovCamera::timeChanged(time) applied to the camera `origin` -- camera.cpp:88-94."""
+    out = CameraC()
+    _chk(lib().rt_camera_change_fov(C.byref(origin), C.c_double(time), C.byref(out)), "rt_camera_change_fov")
+    return out
+
+
+def light_move_face(origin, time):
+    """MovableFaceLight at `time` (light.cpp:87-107); `origin` and the result are LIGHT_DT records."""
+    from .desc import LIGHT_DT
+    src = np.ascontiguousarray(np.asarray(origin, LIGHT_DT).reshape(1))
+    out = np.zeros(1, LIGHT_DT)
+    _chk(lib().rt_light_move_face(src.ctypes.data_as(C.c_void_p), C.c_double(time), out.ctypes.data_as(C.c_void_p)), "rt_light_move_face")
+    return out[0]
 
 
 def save_bmp(bgr, filename):
@@ -189,6 +209,12 @@ class HipScene:
         out = (C.c_double * 6)()
         _chk(lib().rt_scene_get_profile(self._h, out, 1 if reset else 0), "rt_scene_get_profile")
         return dict(zip(("trace_launches", "trace_ms", "shade_launches", "shade_ms", "generate_launches", "rounds"), out[:]))
+
+    def set_light(self, index, light, stream=0):
+        """Replace light `index` (a LIGHT_DT record) of the uploaded scene."""
+        from .desc import LIGHT_DT
+        rec = np.ascontiguousarray(np.asarray(light, LIGHT_DT).reshape(1))
+        _chk(lib().rt_scene_set_light(self._h, C.c_uint64(index), rec.ctypes.data_as(C.c_void_p), stream or None), "rt_scene_set_light")
 
     def check(self, stream=0):
         _chk(lib().rt_scene_check(self._h, stream or None), "rt_scene_check")

@@ -1,5 +1,10 @@
-"""Multi-GPU sharding of the path-tracing path: one process per GPU, samples-per-pixel
-partitioned across ranks, one sum-reduce of the full-frame radiance buffers to rank 0.
+"""Multi-GPU sharding of the path-tracing path, one process per GPU.  Two partitions:
+
+* a still frame: samples-per-pixel partitioned across ranks, one sum-reduce of the full-frame
+  radiance buffers to rank 0;
+* an animation (the reference driver's loop over `time`, main.cpp:83-101): whole frames dealt
+  round-robin, frame f to rank f mod world.  Frames are independent, so the data path has no
+  collective; the finished 8-bit frames are gathered to rank 0 only to be written in order.
 
 Every (pixel, sample) is independent in the reference; the only coupling is the per-pixel
 average and the clamp that follows it (scene.cpp:112-113), so partial sums are reduced
@@ -48,3 +53,45 @@ def render_sharded(render_slice, total_samples, buf, rank=None, world=None, dst=
     if e > b:
         render_slice(b, e, buf)
     return reduce_radiance(buf, dst)
+
+
+def frame_slice(rank, world, nframes):
+    """Frame numbers of `rank`: f with f mod world == rank, ascending."""
+    if world <= 0 or not (0 <= rank < world) or nframes < 0:
+        raise ValueError("bad rank / world / nframes")
+    return list(range(rank, nframes, world))
+
+
+def frame_times(nframes, dt=0.015, t0=0.0):
+    """The clock of the reference's animation loop (main.cpp:83: `time += 0.015` from 0), as the
+    same running sum so that frame f sees the bit-identical `time` on whichever rank renders it."""
+    out, t = [], float(t0)
+    for _ in range(nframes):
+        out.append(t)
+        t += dt
+    return out
+
+
+def render_frames(render_frame, nframes, rank=None, world=None, dst=0, dt=0.015):
+    """Render an animation frame-partitioned: this rank calls `render_frame(f, time)` for its
+    frames (each call returns the frame as an array) and rank `dst` receives all of them in frame
+    order; other ranks get None.  No collective runs while frames are being rendered."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized()
+    if rank is None:
+        rank = dist.get_rank() if on else 0
+    if world is None:
+        world = dist.get_world_size() if on else 1
+    times = frame_times(nframes, dt)
+    mine = [(f, render_frame(f, times[f])) for f in frame_slice(rank, world, nframes)]
+    if not on or world == 1:
+        return [img for _, img in mine]
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(mine, parts, dst=dst)
+    if rank != dst:
+        return None
+    frames = [None] * nframes
+    for part in parts:
+        for f, img in part:
+            frames[f] = img
+    return frames

@@ -350,6 +350,26 @@ def phong_scene(light="point"):
     return desc, cam
 
 
+def animation_scene(width=160, height=120):
+    """Scene of examples/main_animation.cpp: Phong sphere, Phong + mirror sphere, glass sphere on
+    a Phong ground in front of two walls, a point Light (index 0) and a MovableFaceLight (index 1,
+    light.cpp:87-107), seen through a ChangeFovCamera (camera.cpp:74-94).  Returns the
+    description at time 0, the camera arguments and the index of the moving light."""
+    mats = [phong_material((.10, .04, .04), (.70, .25, .25), (.5, .5, .5), 24.0),
+            phong_material((.02, .02, .02), (.10, .10, .12), (.6, .6, .6), 60.0, mirror=(.75, .75, .8)),
+            glass_material((.02, .03, .05), 1.5),
+            phong_material((.05, .05, .06), (.50, .50, .60), (.1, .1, .1), 4.0),
+            phong_material((.05, .06, .05), (.45, .55, .40), (.2, .2, .2), 8.0)]
+    objs = [sphere((0, 1, 0), 1.0, 0), sphere((2.3, 1, 0.4), 1.0, 1), sphere((-2.3, 1, 0.8), 1.0, 2),
+            plane(OBJ_GROUND, 0.0, 3), plane(OBJ_WALL_Z, -4.0, 4), plane(OBJ_WALL_X, -6.0, 4)]
+    lights = [point_light((4, 7, 5), (.5, .5, .5), (.9, .9, .8), (1, 1, 1)),
+              face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, (.5, .5, .6), ambient=(.2, .2, .2), specular=(.5, .5, .5))]
+    desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [],
+                     background=(0.05, 0.07, 0.1))
+    cam = dict(look_from=(0.5, 2.8, 9), look_at=(0, 1.2, 0), vup=(0, 1, 0), vfov=30.0, aspect=width * 1.0 / height)
+    return desc, cam, 1
+
+
 def kaleidoscope_scene(width=1020, height=630):
     """The reference driver's own scene (main.cpp:29-72): two huge mirror spheres and three
     coloured, mirror-finished SphereLights."""

@@ -140,3 +140,28 @@ def test_product_does_not_touch_the_oracle():
     assert not bad, bad
     out = subprocess.check_output(["ldd", hip.LIB_PATH]).decode()
     assert "oracle" not in out
+
+
+def test_animated_camera_and_light_are_host_arithmetic_and_match_oracle():
+    """ChangeFovCamera::timeChanged (camera.cpp:88-94) and MovableFaceLight (light.cpp:87-107)
+    as host functions of the boundary: same bytes as the oracle's, closed form checked."""
+    cam = dict(look_from=(1, 2, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=40.0, aspect=1.5)
+    a0, b0 = hip.camera_init(**cam), orc.camera_init(**cam)
+    assert bytes(a0) == bytes(b0) and a0.aperture == 0.0 and tuple(a0.look_at) == (0.0, 1.0, 0.0)
+    t = 0.0
+    for _ in range(140):                                   # the driver's clock, main.cpp:83
+        a, b = hip.camera_change_fov(a0, t), orc.camera_change_fov(b0, t)
+        assert bytes(a) == bytes(b)
+        scale = np.sqrt(np.sin(t * 2 * 3.1415926) * 1.5 + 1.6) + 0.3
+        assert a.width == a0.width * scale and a.height == a0.height * scale
+        assert tuple(a.e) == tuple(a0.e) and tuple(a.u) == tuple(a0.u)
+        centre = np.array(a.llc) + np.array(a.u) * a.width / 2 + np.array(a.v) * a.height / 2
+        assert np.allclose(centre, a.look_at, atol=1e-12)
+        t += 0.015
+    l0 = scenes.face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, (.5, .5, .6))
+    for t in (0.0, 0.015, 0.25, 0.5, 1.37, 2.0):
+        a, b = hip.light_move_face(l0, t), orc.light_move_face(l0, t)
+        assert a.tobytes() == b.tobytes()
+        r = np.sqrt(18.0)
+        assert a["pos"][0] == np.sin(t * 2 * 3.1415926) * r and a["pos"][2] == np.cos(t * 2 * 3.1415926) * r
+        assert a["pos"][1] == 6.0 and np.array_equal(a["normal"], l0["normal"]) and a["width"] == 2.5

@@ -70,3 +70,79 @@ def test_two_rank_sample_partition_matches_single_rank(tmp_path):
     assert np.allclose(got, whole, rtol=1e-13, atol=1e-15)
     # resolve after the reduce: identical bytes
     assert np.array_equal(orc.resolve_bgr8(got, n * n), orc.resolve_bgr8(whole, n * n))
+
+
+def test_frame_slices_deal_frames_round_robin():
+    from raytracer_amd.parallel import frame_slice, frame_times
+    for nframes in (0, 1, 7, 8, 134):
+        for world in (1, 2, 3, 8):
+            sl = [frame_slice(r, world, nframes) for r in range(world)]
+            assert sorted(f for s in sl for f in s) == list(range(nframes))
+            assert all(f % world == r for r, s in enumerate(sl) for f in s)
+    t = frame_times(134)
+    acc = 0.0
+    for f in range(134):                                   # the running sum of main.cpp:83, not f * 0.015
+        assert t[f] == acc
+        acc += 0.015
+    assert t[133] <= 2.0 < acc
+
+
+def _animation(scenes_mod):
+    """A scene with a MovableFaceLight (light 1) seen through a ChangeFovCamera."""
+    desc, cam = scenes_mod.phong_scene("face")
+    return desc, cam, 1
+
+
+def _frame_worker(rank, world, port, W, H, n, nframes, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import orc
+    from raytracer_amd import scenes
+    from raytracer_amd.desc import render_params
+    from raytracer_amd.parallel import render_frames
+    desc, cam, li = _animation(scenes)
+    c0 = orc.camera_init(**cam)
+    l0 = desc.lights[li].copy()
+
+    def render_frame(f, time):
+        desc.lights[li] = orc.light_move_face(l0, time)
+        img, _ = orc.OracleScene(desc).render(orc.camera_change_fov(c0, time), render_params(W, H, n, seed=3, max_jump=6), threads=2)
+        return orc.resolve_bgr8(img, n * n)
+
+    frames = render_frames(render_frame, nframes)
+    if rank == 0:
+        np.save(out_path, np.stack(frames))
+    else:
+        assert frames is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_frame_partition_matches_single_rank(tmp_path):
+    """Animation frames dealt round-robin over two gloo ranks (frame f on rank f mod 2), gathered
+    in order on rank 0: byte-identical to rendering the frames one after another."""
+    from oracle import orc
+    from raytracer_amd import scenes
+    from raytracer_amd.desc import render_params
+    from raytracer_amd.parallel import render_frames
+    W, H, n, nframes = 16, 12, 2, 5
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_frame_worker, args=(2, port, W, H, n, nframes, out), nprocs=2, join=True)
+    got = np.load(out)
+    desc, cam, li = _animation(scenes)
+    c0 = orc.camera_init(**cam)
+    l0 = desc.lights[li].copy()
+
+    def render_frame(f, time):
+        desc.lights[li] = orc.light_move_face(l0, time)
+        img, _ = orc.OracleScene(desc).render(orc.camera_change_fov(c0, time), render_params(W, H, n, seed=3, max_jump=6), threads=2)
+        return orc.resolve_bgr8(img, n * n)
+
+    whole = np.stack(render_frames(render_frame, nframes, rank=0, world=1))
+    assert got.shape == (nframes, H, W, 3) and np.array_equal(got, whole)
+    assert not np.array_equal(got[0], got[3])               # the animation does move

@@ -399,3 +399,78 @@ def test_cpp_scene_api_example_matches_oracle(tmp_path):
     exp = orc.resolve_bgr8(img, n * n)
     assert (got != exp).mean() < 2e-3           # a last-bit radiance difference may flip a byte
     assert exp.max() > 20
+
+
+def test_depth_camera_lens_render():
+    """DepthCamera (camera.cpp:50-72): the ray origin is drawn on the lens disk per sample."""
+    desc, cam = scenes.three_sphere_scene("face")
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    co, cg = orc.camera_init(**cam), hip.camera_init(**cam)
+    co.aperture = cg.aperture = 0.35
+    W, H, n = 64, 48, 4
+    prm = render_params(W, H, n, seed=5)
+    i1, k1 = so.render(co, prm)
+    i2, k2 = sg.render(cg, prm)
+    assert np.array_equal(k1, k2)
+    assert np.sqrt((((i1 - i2) / (n * n)) ** 2).mean()) <= RMSE_TOL
+    assert (_rel(i1, i2) > PATH_RTOL).mean() <= 1e-3
+    pin, _ = sg.render(hip.camera_init(**cam), prm)
+    assert not np.array_equal(pin, i2)
+
+
+@pytest.mark.parametrize("which", ["phong", "montecarlo"])
+def test_animation_frames_moving_light_and_changing_fov(which):
+    """The driver's animation loop (main.cpp:83-101): per frame the MovableFaceLight is patched
+    into the uploaded scene (rt_scene_set_light) and the ChangeFovCamera rescales its film; every
+    frame must equal the oracle's render of a scene built afresh for that time."""
+    from raytracer_amd.parallel import frame_times
+    if which == "phong":
+        desc, cam, li = scenes.animation_scene(64, 48)
+    else:
+        desc, cam = scenes.three_sphere_scene("face")
+        li = 0
+    sg = hip.HipScene(desc)
+    c0 = hip.camera_init(**cam)
+    l0 = desc.lights[li].copy()
+    W, H, n = 64, 48, 2
+    prm = render_params(W, H, n, seed=9, max_jump=10)
+    frames = []
+    for f, time in enumerate(frame_times(40)):
+        if f % 13:
+            continue
+        lt = hip.light_move_face(l0, time)
+        sg.set_light(li, lt)
+        i2, k2 = sg.render(hip.camera_change_fov(c0, time), prm)
+        desc.lights[li] = lt
+        i1, k1 = orc.OracleScene(desc).render(orc.camera_change_fov(orc.camera_init(**cam), time), prm)
+        assert np.array_equal(k1, k2), f
+        assert np.sqrt((((i1 - i2) / (n * n)) ** 2).mean()) <= RMSE_TOL
+        assert (_rel(i1, i2) > PATH_RTOL).mean() <= 1e-3
+        frames.append(i2)
+    assert not np.array_equal(frames[0], frames[1])
+    with pytest.raises(RuntimeError):
+        sg.set_light(7, l0)
+
+
+def test_cpp_animation_example_matches_oracle(tmp_path):
+    """examples/main_animation (ChangeFovCamera + MovableFaceLight through Scene::setTime of
+    include/rt_scene.hpp, its own process) against the oracle, frame by frame."""
+    import subprocess
+    from raytracer_amd.parallel import frame_times
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "main_animation")
+    assert os.path.exists(exe), "examples/main_animation is not built (__graft_entry__.build())"
+    W, H, n, nframes = 80, 60, 2, 4
+    subprocess.check_call([exe, str(W), str(H), str(n), str(nframes), str(tmp_path / "f_")], timeout=120)
+    desc, cam, li = scenes.animation_scene(W, H)
+    l0 = desc.lights[li].copy()
+    c0 = orc.camera_init(**cam)
+    prev = None
+    for f, time in enumerate(frame_times(nframes)):
+        raw = open(tmp_path / f"f_{f:03d}.bmp", "rb").read()
+        got = np.frombuffer(raw[54:], np.uint8).reshape(H, W, 3)
+        desc.lights[li] = orc.light_move_face(l0, time)
+        img, _ = orc.OracleScene(desc).render(orc.camera_change_fov(c0, time), render_params(W, H, n, seed=1243))
+        exp = orc.resolve_bgr8(img, n * n)
+        assert (got != exp).mean() < 2e-3, f
+        assert prev is None or not np.array_equal(prev, got)
+        prev = got

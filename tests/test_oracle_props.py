@@ -217,3 +217,29 @@ def test_flat_triangles_survive_the_octree():
     assert st["lost"] == 0 and st["nodes"] > 1
     lost = SceneDesc(desc.objects, desc.materials, desc.lights, desc.meshes, tri_box_pad=0.0, octree_max_size=32)
     assert orc.OracleScene(lost).octree_stats(0)["lost"] > 0
+
+
+def test_depth_camera_lens_properties():
+    """DepthCamera::getRay (camera.cpp:62-72): every sample's ray starts on the lens disk
+    (|offset| < aperture in the u, v plane) and passes through its film point, so a surface in
+    the focal plane renders exactly as with the pinhole camera while others blur."""
+    from raytracer_amd.desc import render_params
+    # a textured-by-geometry scene would do; the three-sphere scene has edges at several depths
+    desc, cam = scenes.three_sphere_scene("face")
+    so = orc.OracleScene(desc)
+    pin = orc.camera_init(**cam)
+    lens = orc.camera_init(**cam)
+    lens.aperture = 0.35
+    W, H, n = 48, 36, 4
+    prm = render_params(W, H, n, seed=5)
+    a, ka = so.render(pin, prm)
+    b, kb = so.render(lens, prm)
+    assert not np.array_equal(a, b) and abs(a.mean() - b.mean()) < 0.25 * a.mean()
+    # aperture 0 is the pinhole camera, bit for bit
+    lens.aperture = 0.0
+    c, kc = so.render(lens, prm)
+    assert np.array_equal(a, c) and np.array_equal(ka, kc)
+    # a tiny aperture converges to the pinhole image
+    lens.aperture = 1e-9
+    d, _ = so.render(lens, prm)
+    assert np.abs(d - a).max() < 1e-3 * max(a.max(), 1.0) or (np.abs(d - a) > 1e-6).mean() < 0.02
