@@ -25,9 +25,16 @@ extern "C" {
 
 /* Material::Type bit flags -- material.h:10-16 */
 enum { RT_MAT_NORMAL = 1, RT_MAT_SPECULAR = 2, RT_MAT_TRANSPARENT = 4, RT_MAT_MONTECARLO = 8 };
-/* Node kinds -- Surface.h:50-56; RT_OBJ_MESH is the triangle mesh drawable this library adds
- * where the reference has HeartShape / ImplicitSurface (Surface.h:131-174) */
-enum { RT_OBJ_SPHERE = 1, RT_OBJ_GROUND = 2, RT_OBJ_WALL_Z = 3, RT_OBJ_WALL_X = 4, RT_OBJ_MESH = 5 };
+/* Node kinds -- Surface.h:50-56; RT_OBJ_MESH is the triangle mesh drawable this library adds;
+ * RT_OBJ_HEART = HeartShape (Surface.h:151-174), RT_OBJ_GENUS2 = SurfaceOfGenus2
+ * (ImplicitSurface<SurfaceOfGenus2Function>, Surface.h:121-147): implicit surfaces intersected
+ * through an octree of voxels (ImplicitSurfaceOctree, octree.cpp:148-254), one tree per kind
+ * shared by all objects of the kind (the static ptree of the reference classes). */
+enum { RT_OBJ_SPHERE = 1, RT_OBJ_GROUND = 2, RT_OBJ_WALL_Z = 3, RT_OBJ_WALL_X = 4, RT_OBJ_MESH = 5,
+       RT_OBJ_HEART = 6, RT_OBJ_GENUS2 = 7 };
+/* NormalCheckMaterial / PositionCheckMaterial (material.h:70-92): getAmbient() returns |normal|,
+ * or the hit's local position relative to check_box, instead of the stored ambient colour */
+enum { RT_CHECK_NONE = 0, RT_CHECK_NORMAL = 1, RT_CHECK_POSITION = 2 };
 /* SphereLight / FaceLight / the point Light -- light.h:8-73 */
 enum { RT_LIGHT_SPHERE = 1, RT_LIGHT_FACE = 2, RT_LIGHT_POINT = 3 };
 
@@ -39,7 +46,8 @@ typedef struct {
     int32_t material;  /* Node::setMaterial, Surface.cpp:25-31 */
     int32_t mesh;      /* index into rt_scene_desc.meshes (RT_OBJ_MESH only) */
     int32_t reserved;
-    double  p[4];      /* Sphere(center, radius): cx,cy,cz,r (Surface.h:98) ; Ground(y) / Wall_z(z) / Wall_x(x): p[0] */
+    double  p[4];      /* Sphere(center, radius): cx,cy,cz,r (Surface.h:98) ; Ground(y) / Wall_z(z) / Wall_x(x): p[0] ;
+                          HeartShape / SurfaceOfGenus2 (center, scale): cx,cy,cz,scale */
 } rt_object;
 
 /* Plain Material -- material.h:55-66, ctors material.cpp:2-23.  With RT_MAT_MONTECARLO in
@@ -47,7 +55,7 @@ typedef struct {
  * it the Phong / Whitted branch (scene.cpp:305-375), which reads the last four fields. */
 typedef struct {
     int32_t type;
-    int32_t reserved;
+    int32_t check;       /* RT_CHECK_* */
     double  emission[3];
     double  color[3];    /* getColor() == getDiffuse() */
     double  blur;        /* getMirrorBlur() */
@@ -57,6 +65,7 @@ typedef struct {
     double  specular[3]; /* getSpecular() */
     double  mirror[3];   /* getMirror() */
     double  shine;       /* getShine() */
+    double  check_box[6];/* PositionCheckMaterial(box): lower corner, upper corner */
 } rt_material;
 
 /* SphereLight(pos, radius, emission) light.cpp:109-116 ; FaceLight(...) light.cpp:50-56 ;
@@ -93,6 +102,8 @@ typedef struct {
     int32_t octree_overlap_tol; /* OctreeNode::OverlapTolerance = 3, octree.h:26 */
     int32_t octree_max_depth;   /* depth guard (the reference has none), <= 15 */
     int32_t reserved;
+    double  implicit_min_size;  /* half edge of an implicit surface's voxels; 0 = 3e-3, the value both reference
+                                   surfaces use (octree.h:66, Surface.h:123) */
 } rt_scene_desc;
 
 /* Camera members after Camera::init -- camera.cpp:37-48 */
@@ -135,6 +146,12 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
 int rt_scene_destroy(rt_scene *scene);
 /* out[0..5] = nodes, leaves, object refs, refs at inner nodes, max depth, lost primitives */
 int rt_scene_octree_stats(const rt_scene *scene, int mesh, uint64_t out[6]);
+/* The voxel octree of the scene's implicit surfaces of one kind (RT_OBJ_HEART / RT_OBJ_GENUS2),
+ * built by ImplicitSurfaceOctree::build's rule (octree.cpp:148-254): the same six numbers, and the
+ * voxels in insertion order, 6 doubles each (lower, upper corner); returns the voxel count
+ * (writing at most `cap` of them) or a negative error. */
+int rt_scene_implicit_stats(const rt_scene *scene, int kind, uint64_t out[6]);
+int64_t rt_scene_implicit_boxes(const rt_scene *scene, int kind, double *boxes, uint64_t cap);
 
 /* Camera::Camera -> init, camera.cpp:5-8,37-48 (host arithmetic) */
 int rt_camera_init(const double look_from[3], const double look_at[3], const double vup[3],

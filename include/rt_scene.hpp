@@ -80,11 +80,32 @@ public:
         if (emission.x_ >= 0) set3(rec_.emission, emission);
     }
     void setMirrorBlur(double b) { rec_.blur = b; }
+protected:
+    void setCheck(int kind) { rec_.check = kind; }
+    void setCheckBox(const Vec3 &lo, const Vec3 &hi)
+    {
+        rec_.check_box[0] = lo.x_; rec_.check_box[1] = lo.y_; rec_.check_box[2] = lo.z_;
+        rec_.check_box[3] = hi.x_; rec_.check_box[4] = hi.y_; rec_.check_box[5] = hi.z_;
+    }
+public:
     int getType() const { return rec_.type; }
     const rt_material &record() const { return rec_; }
 private:
     static void set3(double *d, const Color &c) { d[0] = c.x_; d[1] = c.y_; d[2] = c.z_; }
     rt_material rec_;
+};
+
+// material.h:70-92: debug materials whose ambient colour shows the normal / the local position
+class NormalCheckMaterial : public Material {
+public:
+    NormalCheckMaterial() : Material(Color(0, 0, 0, 1), Color(0, 0, 0, 1), Color(0, 0, 0, 1), 1) { setCheck(RT_CHECK_NORMAL); }
+};
+class PositionCheckMaterial : public Material {
+public:
+    PositionCheckMaterial(Vec3 lo, Vec3 hi) : Material(Color(0, 0, 0, 1), Color(0, 0, 0, 1), Color(0, 0, 0, 1), 1)
+    {
+        setCheck(RT_CHECK_POSITION); setCheckBox(lo, hi);
+    }
 };
 
 // Surface.h:47-74
@@ -135,6 +156,24 @@ public:
 private:
     double c_;
 };
+// HeartShape(center, scale), Surface.h:151-174; SurfaceOfGenus2(center, scale), Surface.h:129-147:
+// implicit surfaces intersected through a voxel octree that the library builds at upload
+template <int KIND> class Implicit_ : public Drawable {
+public:
+    Implicit_(Vec3 center, double scale) : c_(center), s_(scale) {}
+    int flatten(std::vector<rt_object> &objs, std::vector<rt_material> &mats, std::vector<std::vector<double>> &) const override
+    {
+        rt_object o{}; o.type = KIND; o.mesh = -1;
+        if ((o.material = material_index(mats)) < 0) return -1;
+        o.p[0] = c_.x_; o.p[1] = c_.y_; o.p[2] = c_.z_; o.p[3] = s_;
+        objs.push_back(o);
+        return 0;
+    }
+private:
+    Vec3 c_; double s_;
+};
+using HeartShape = Implicit_<RT_OBJ_HEART>;
+using SurfaceOfGenus2 = Implicit_<RT_OBJ_GENUS2>;
 using Ground = Plane_<RT_OBJ_GROUND>;
 using Wall_z = Plane_<RT_OBJ_WALL_Z>;
 using Wall_x = Plane_<RT_OBJ_WALL_X>;
@@ -285,6 +324,7 @@ public:
     void setSeed(uint64_t s) { seed_ = s; }
     void setFaceForward(bool on) { faceForward_ = on; }
     void setOctree(int maxSize, int maxDepth) { octMax_ = maxSize; octDepth_ = maxDepth; dirty_ = true; }
+    void setImplicitMinSize(double s) { implicitMin_ = s; dirty_ = true; }      // octree.h:66 (3e-3 when 0)
     // RTObject::setTime cascade (RTObject.h:110-117, main.cpp:85): the camera and the lights follow
     // the clock; a moved light is patched into the uploaded scene, nothing is rebuilt.
     int setTime(double time)
@@ -350,6 +390,7 @@ private:
         d.meshes = mrec.data(); d.nmeshes = mrec.size();
         d.background[0] = background_.x_; d.background[1] = background_.y_; d.background[2] = background_.z_;
         d.tri_box_pad = 1e-7; d.octree_max_size = octMax_; d.octree_overlap_tol = 3; d.octree_max_depth = octDepth_;
+        d.implicit_min_size = implicitMin_;
         if (rt_scene_create(&d, &handle_)) return -1;
         dirty_ = false;
         return 0;
@@ -362,6 +403,7 @@ private:
     bool run_ = false, dirty_ = true, faceForward_ = false;
     int n_ = 20, m_ = 20, maxJump_ = 40, rusJump_ = 12;                      // scene.h:52-54
     int octMax_ = 128, octDepth_ = 12;                                       // octree.h:50
+    double implicitMin_ = 0;
     uint64_t seed_ = 1243;                                                   // scene.cpp:22
     rt_scene *handle_ = nullptr;
     std::vector<double> sum_;

@@ -40,6 +40,12 @@ def lib():
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
         L.orc_octree_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_implicit_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.orc_implicit_boxes.restype = C.c_int64
+        L.orc_implicit_boxes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+        L.orc_implicit_func.restype = C.c_double
+        L.orc_implicit_func.argtypes = [C.c_int, _dp]
+        L.orc_implicit_normal.argtypes = [C.c_int, _dp, _dp]
         L.orc_camera_init.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(CameraC)]
         L.orc_camera_get_ray.argtypes = [C.POINTER(CameraC), C.c_double, C.c_double, C.c_void_p]
         L.orc_camera_change_fov.argtypes = [C.POINTER(CameraC), C.c_double, C.POINTER(CameraC)]
@@ -106,6 +112,19 @@ class OracleScene:
         self._chk(lib().orc_octree_stats(self._h, mesh, out), "orc_octree_stats")
         return dict(zip(("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost"), [int(x) for x in out]))
 
+    def implicit_stats(self, kind):
+        out = (C.c_uint64 * 6)()
+        self._chk(lib().orc_implicit_stats(self._h, kind, out), "orc_implicit_stats")
+        return dict(zip(("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost"), [int(x) for x in out]))
+
+    def implicit_boxes(self, kind):
+        n = lib().orc_implicit_boxes(self._h, kind, None, 0)
+        if n < 0:
+            raise RuntimeError("orc_implicit_boxes: " + lib().orc_last_error().decode())
+        out = np.empty((n, 6), np.float64)
+        lib().orc_implicit_boxes(self._h, kind, _p(out), n)
+        return out
+
     def trace_rays(self, rays, t0=0.0, t1=1e10):
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)
         n = len(rays)
@@ -156,6 +175,16 @@ def light_move_face(origin, time):
     out = np.zeros(1, LIGHT_DT)
     lib().orc_light_move_face(src.ctypes.data_as(C.c_void_p), C.c_double(time), out.ctypes.data_as(C.c_void_p))
     return out[0]
+
+
+def implicit_func(kind, pos):
+    return lib().orc_implicit_func(kind, _d3(pos))
+
+
+def implicit_normal(kind, pos):
+    out = (C.c_double * 3)()
+    lib().orc_implicit_normal(kind, _d3(pos), out)
+    return np.array(out[:])
 
 
 def camera_get_ray(cam, s, t):
@@ -261,6 +290,17 @@ def ref():
         R.ref_tree_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         R.ref_tree_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         R.ref_group_hit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        R.ref_implicit_create.restype = C.c_void_p
+        R.ref_implicit_create.argtypes = [C.c_int, C.c_double]
+        R.ref_implicit_destroy.argtypes = [C.c_void_p]
+        R.ref_implicit_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        R.ref_implicit_boxes.restype = C.c_int64
+        R.ref_implicit_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        R.ref_implicit_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        R.ref_implicit_func.restype = C.c_double
+        R.ref_implicit_func.argtypes = [C.c_int, _dp]
+        R.ref_implicit_object_hit.argtypes = [C.c_int, _dp, C.c_double, C.c_void_p, C.c_uint64, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for f in ("ref_const_zero", "ref_const_infinite", "ref_const_pi"):
             getattr(R, f).restype = C.c_double
         _ref = R
@@ -359,3 +399,53 @@ def ref_group_hit(objs, rays, t0=0.0, t1=1e10):
     which = np.empty(n, np.int32); t = np.empty(n, np.float64); nrm = np.empty((n, 3), np.float64)
     ref().ref_group_hit(_p(objs), len(objs), _p(rays), n, t0, t1, _p(which), _p(t), _p(nrm))
     return which, t, nrm
+
+
+def _rays_flat(rays):
+    return np.ascontiguousarray(rays, dtype=RAY_DT)
+
+
+class RefImplicit:
+    """The reference's ImplicitSurfaceOctree over one of its own implicit functions."""
+
+    def __init__(self, kind, min_size):
+        self._h = ref().ref_implicit_create(kind, float(min_size))
+        if not self._h:
+            raise RuntimeError("ref_implicit_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            ref().ref_implicit_destroy(self._h)
+            self._h = None
+
+    def stats(self):
+        out = (C.c_uint64 * 6)()
+        ref().ref_implicit_stats(self._h, out)
+        return dict(zip(("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost"), [int(x) for x in out]))
+
+    def boxes(self):
+        n = ref().ref_implicit_boxes(self._h, None, 0)
+        out = np.empty((n, 6), np.float64)
+        ref().ref_implicit_boxes(self._h, _p(out), n)
+        return out
+
+    def hit(self, rays, t0=0.0, t1=1e10):
+        flat = _rays_flat(rays)
+        n = len(flat)
+        hit = np.zeros(n, np.int32); t = np.zeros(n, np.float64)
+        ref().ref_implicit_hit(self._h, _p(flat), n, t0, t1, _p(hit), _p(t))
+        return hit, t
+
+
+def ref_implicit_func(kind, pos):
+    return ref().ref_implicit_func(kind, _d3(pos))
+
+
+def ref_implicit_object_hit(kind, center, scale, rays, t0=0.0, t1=1e10):
+    """HeartShape / SurfaceOfGenus2 through Node::calHit: hit flags, t, normals, localp."""
+    flat = _rays_flat(rays)
+    n = len(flat)
+    hit = np.zeros(n, np.int32); t = np.zeros(n, np.float64)
+    nrm = np.zeros((n, 3), np.float64); lp = np.zeros((n, 3), np.float64)
+    ref().ref_implicit_object_hit(kind, _d3(center), float(scale), _p(flat), n, t0, t1, _p(hit), _p(t), _p(nrm), _p(lp))
+    return hit, t, nrm, lp

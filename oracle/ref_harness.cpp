@@ -289,6 +289,89 @@ void ref_group_hit(const double *objs, int nobj, const double *rays, uint64_t n,
     }
 }
 
+// ---- implicit surfaces: the reference's own voxel octree (ImplicitSurfaceOctree::build,
+// octree.cpp:148-254) over its own implicit functions; kind 6 = HeartShape, 7 = SurfaceOfGenus2
+struct RefImplicit {
+    ImplicitSurfaceOctree *tree;
+    SurfaceOfGenus2Function g2;
+};
+void *ref_implicit_create(int kind, double min_size)
+{
+    RefImplicit *r = new RefImplicit;
+    if (kind == 6) {
+        Point_t seedp[2]{ Vec3(0, 0, 0), Vec3(2, 0, 0) };                      // Surface.cpp:302
+        r->tree = new ImplicitSurfaceOctree(HeartShape::heartImplicitFunc, seedp, min_size);
+    } else {
+        Point_t seedp[2]{ r->g2.getSeedPoint(0), r->g2.getSeedPoint(1) };       // Surface.h:321
+        r->tree = new ImplicitSurfaceOctree(std::bind(&SurfaceOfGenus2Function::ImplicitFunc, &r->g2, std::placeholders::_1), seedp, min_size);
+    }
+    if (r->tree->build()) { delete r->tree; delete r; return nullptr; }
+    return r;
+}
+void ref_implicit_destroy(void *h) { RefImplicit *r = (RefImplicit *)h; delete r->tree; delete r; }
+void ref_implicit_stats(void *h, uint64_t out[6])
+{
+    memset(out, 0, 6 * sizeof(uint64_t));
+    walk(((RefImplicit *)h)->tree->root_.get(), 0, out);
+}
+namespace {
+struct BoxLess { bool operator()(const BoxNode *a, const BoxNode *b) const { return *a < *b; } };
+void collect(const OctreeNode *n, std::set<const BoxNode *, BoxLess> &all)
+{
+    for (const auto &o : n->objects_) all.insert(static_cast<const BoxNode *>(o.get()));
+    if (n->isLeaf()) return;
+    for (int i = 0; i < 8; i++) collect(n->children_[i].get(), all);
+}
+}
+// the voxels in the order of the reference's std::set (BoxNode::operator<): 6 doubles each
+int64_t ref_implicit_boxes(void *h, double *boxes, uint64_t cap)
+{
+    std::set<const BoxNode *, BoxLess> all;
+    collect(((RefImplicit *)h)->tree->root_.get(), all);
+    uint64_t i = 0;
+    for (const BoxNode *b : all) {
+        if (i < cap) { st(boxes + 6 * i, b->box_[0]); st(boxes + 6 * i + 3, b->box_[1]); }
+        i++;
+    }
+    return (int64_t)i;
+}
+// Octree::hit on the voxel tree (BoxNode::calHit payload, Surface.cpp:43-59)
+void ref_implicit_hit(void *h, const double *rays, uint64_t n, double t0, double t1, int32_t *hit, double *tout)
+{
+    RefImplicit *r = (RefImplicit *)h;
+    for (uint64_t i = 0; i < n; i++) {
+        HitRecord rec;
+        hit[i] = r->tree->hit(mkray(rays + 6 * i), t0, t1, &rec) ? 1 : 0;
+        tout[i] = hit[i] ? rec.t : INFINITE;
+    }
+}
+double ref_implicit_func(int kind, const double pos[3])
+{
+    if (kind == 6) return HeartShape::heartImplicitFunc(v3(pos));
+    SurfaceOfGenus2Function f;
+    return f.ImplicitFunc(v3(pos));
+}
+// The drawables themselves through Node::calHit (Surface.h:272-283): ray taken into the
+// surface's frame, shared tree (built on first use with the reference's default voxel size),
+// analytic normal, localp (HeartShape only).  The reference prints diagnostics to stdout from
+// HeartShape::getRawNormal for some points; they are left alone.
+void ref_implicit_object_hit(int kind, const double center[3], double scale, const double *rays, uint64_t n,
+                             double t0, double t1, int32_t *hit, double *tout, double *normal, double *localp)
+{
+    std::shared_ptr<Drawable> d;
+    if (kind == 6) d = std::make_shared<HeartShape>(v3(center), scale);
+    else d = std::make_shared<SurfaceOfGenus2>(v3(center), scale);
+    for (uint64_t i = 0; i < n; i++) {
+        HitRecord rec;
+        Ray r = mkray(rays + 6 * i);
+        rec.ray = r;
+        hit[i] = d->calHit(r, t0, t1, &rec) ? 1 : 0;
+        tout[i] = hit[i] ? rec.t : INFINITE;
+        st(normal + 3 * i, hit[i] ? rec.normal : Vec3(0, 0, 0));
+        st(localp + 3 * i, hit[i] ? rec.localp : Vec3(0, 0, 0));
+    }
+}
+
 // RTObject::calRandom structure check (RTObject.cpp:46-69) cannot be run on glibc
 // (RAND_MAX + 1 overflows); only the table layout constants are exposed.
 double ref_const_zero(void) { return ZERO; }

@@ -302,6 +302,7 @@ typedef struct {
     onode *root;
     int max_size, tol, max_depth;
     uint64_t lost;
+    int boxes;            /* the primitives are the boxes blo/bhi themselves (BoxNode) */
 } otree;
 
 static onode *onode_new(v3 lo, v3 hi, int depth)
@@ -364,6 +365,16 @@ static void onode_insert(otree *t, onode *n, uint32_t o)
 
 typedef struct { uint64_t rays, inner, leaf, prim; } counters_t;
 
+/* BoxNode::calHit, Surface.cpp:43-59: a voxel is hit where the ray enters it, moved back towards
+ * the ray origin by the voxel's diagonal (the second assignment of rec->t is the one that counts) */
+static int box_node_hit(v3 lo, v3 hi, ray_t r, double t0, double t1, double *tout)
+{
+    double rt0, rt1;
+    if (!hit_box(lo, hi, r, t0, t1, &rt0, &rt1)) return 0;
+    *tout = rt0 - vlen(vsub(lo, hi)) / vlen(r.d);
+    return 1;
+}
+
 typedef struct {
     double t;
     v3 normal;
@@ -371,6 +382,7 @@ typedef struct {
     int obj;        /* index in group order */
     uint32_t prim;  /* triangle index inside a mesh */
     ray_t ray;
+    v3 localp;      /* written by a HeartShape hit only (Surface.cpp:275) */
 } hitrec;
 
 /* OctreeNode::hit, octree.cpp:19-38.  Returns 1 when some object was hit; best and bprim are
@@ -384,11 +396,17 @@ static int onode_hit(const otree *t, const onode *n, ray_t r, double t0, double 
     int flag = 0;
     for (uint32_t k = 0; k < n->nobj; k++) {
         uint32_t o = n->objs[k];
-        const double *tr = t->tris + 9 * (uint64_t)o;
-        v3 v0 = v3p(tr), v1 = v3p(tr + 3), v2 = v3p(tr + 6);
         double tt;
         if (c) c->prim++;
-        if (triangle_hit(v0, vsub(v1, v0), vsub(v2, v0), r, bt0, bt1, &tt)) {
+        int h;
+        if (t->boxes) {
+            h = box_node_hit(t->blo[o], t->bhi[o], r, bt0, bt1, &tt);
+        } else {
+            const double *tr = t->tris + 9 * (uint64_t)o;
+            v3 v0 = v3p(tr), v1 = v3p(tr + 3), v2 = v3p(tr + 6);
+            h = triangle_hit(v0, vsub(v1, v0), vsub(v2, v0), r, bt0, bt1, &tt);
+        }
+        if (h) {
             flag = 1;
             if (tt <= tempt) { tempt = tt; *best = tt; *bprim = o; }
         }
@@ -458,6 +476,176 @@ static int otree_hit(const otree *t, ray_t r, double t0, double t1, double *tout
     return 0;
 }
 
+/* ------------------------------------------------------------------ implicit surfaces */
+/* HeartShape::heartImplicitFunc (Surface.h:218-224), SurfaceOfGenus2Function::ImplicitFunc
+ * (Surface.cpp:318-325); both swap y and z */
+static double implicit_func(int kind, v3 pos)
+{
+    double x = pos.x, y = pos.z, z = pos.y;
+    if (kind == ORC_OBJ_HEART) {
+        double temp = x * x + y * y * 9.0 / 4 + z * z - 1;
+        return -(x * x * z * z * z) - y * y * z * z * z * 9.0 / 80 + temp * temp * temp;
+    }
+    double temp = x * x + y * y;
+    return 2 * y * (y * y - 3 * x * x) * (1 - z * z) + temp * temp - (9 * z * z - 1) * (1 - z * z);
+}
+double orc_implicit_func(int kind, const double pos[3]) { return implicit_func(kind, v3p(pos)); }
+/* HeartShape::getRawNormal (Surface.cpp:239-265) and SurfaceOfGenus2Function::getNormal
+ * (Surface.cpp:333-343) on a point of the surface's own frame */
+static v3 implicit_normal(int kind, v3 pos)
+{
+    double x = pos.x, y = pos.z, z = pos.y;
+    v3 n;
+    if (kind == ORC_OBJ_HEART) {
+        double temp = x * x + y * y * 9.0 / 4 + z * z - 1;
+        temp = 3 * temp * temp;
+        temp = stdmax(temp, 0.5);
+        n.x = -2 * x * z * z * z + temp * 2 * x;
+        n.z = -9.0 / 40 * y * z * z * z + temp * 9.0 / 2 * y;
+        n.y = -3 * x * x * z * z - 27.0 / 80 * y * y * z * z + 2 * temp * z;
+    } else {
+        n.x = -12 * x * y * (1 - z * z) + 4 * (x * x + y * y) * x;
+        n.z = 6 * (1 - z * z) * (y * y - x * x) + 4 * (x * x + y * y) * y;
+        n.y = 2 * y * (y * y - 3 * x * x) * -2 * z + 36 * z * z * z - 20 * z;
+    }
+    return vnorm(n);
+}
+void orc_implicit_normal(int kind, const double pos[3], double out[3]) { v3st(out, implicit_normal(kind, v3p(pos))); }
+
+/* algorithm::calSingleRoot, algorithms.h:143-172: bisection down to |f| <= 10e-8 */
+static int single_root(int kind, v3 sp, v3 unit, double t1, double t2, double *root)
+{
+#define F(t) implicit_func(kind, vadd(vmul(unit, (t)), sp))
+    double f1 = F(t1), f2 = F(t2);
+    if (f1 == 0.0) { *root = t1; return 0; }
+    if (f2 == 0.0) { *root = t2; return 0; }
+    if (f1 * f2 > 0.0) return -1;
+    double tm = (t1 + t2) / 2, fm = F(tm);
+    while (fabs(fm) > 10e-8) {
+        if (f1 * fm < 0) { t2 = tm; f2 = fm; } else { t1 = tm; f1 = fm; }
+        tm = (t1 + t2) / 2;
+        fm = F(tm);
+    }
+#undef F
+    *root = tm;
+    return 0;
+}
+
+/* algorithm::getAdjBox, algorithms.h:251-278 (faces FRONT, TOP, LEFT, RIGHT, DOWN, BACK) */
+static void adj_box(v3 lo, v3 hi, int face, v3 *alo, v3 *ahi)
+{
+    switch (face) {
+    case 0: *alo = vsub(lo, V(0, hi.y - lo.y, 0)); *ahi = bound_point(5, lo, hi); break;
+    case 1: *alo = bound_point(4, lo, hi); *ahi = vadd(hi, V(0, 0, hi.z - lo.z)); break;
+    case 2: *alo = vsub(lo, V(hi.x - lo.x, 0, 0)); *ahi = bound_point(7, lo, hi); break;
+    case 3: *alo = bound_point(1, lo, hi); *ahi = vadd(hi, V(hi.x - lo.x, 0, 0)); break;
+    case 4: *alo = vsub(lo, V(0, 0, hi.z - lo.z)); *ahi = bound_point(2, lo, hi); break;
+    default: *alo = bound_point(3, lo, hi); *ahi = vadd(hi, V(0, hi.y - lo.y, 0)); break;
+    }
+}
+
+/* The set of voxels, keyed the way BoxNode::operator< (Surface.h:30-44) sees them: two boxes whose
+ * lower corners are closer than 1e-9 are the same element, otherwise they order by x, then y,
+ * then z.  Voxel corners reached along different paths differ by rounding only (~1e-13), distinct
+ * voxels by a whole edge, so the integer cell of the lower corner is an exact key. */
+typedef struct { int64_t ix, iy, iz; uint32_t box; } vcell;
+typedef struct { vcell *slot; uint64_t cap, n; } vset;
+static uint64_t vcell_hash(int64_t x, int64_t y, int64_t z)
+{
+    return mix64((uint64_t)x * 0x9E3779B97F4A7C15ULL ^ mix64((uint64_t)y * 0xC2B2AE3D27D4EB4FULL ^ mix64((uint64_t)z)));
+}
+static int vset_find_or_add(vset *s, int64_t x, int64_t y, int64_t z, uint32_t box, int add)
+{
+    if ((s->n + 1) * 2 > s->cap) {
+        uint64_t ncap = s->cap ? s->cap * 2 : 1024;
+        vcell *ns = (vcell *)malloc(ncap * sizeof(vcell));
+        for (uint64_t i = 0; i < ncap; i++) ns[i].box = ORC_MISS;
+        for (uint64_t i = 0; i < s->cap; i++) {
+            if (s->slot[i].box == ORC_MISS) continue;
+            uint64_t h = vcell_hash(s->slot[i].ix, s->slot[i].iy, s->slot[i].iz) & (ncap - 1);
+            while (ns[h].box != ORC_MISS) h = (h + 1) & (ncap - 1);
+            ns[h] = s->slot[i];
+        }
+        free(s->slot); s->slot = ns; s->cap = ncap;
+    }
+    uint64_t h = vcell_hash(x, y, z) & (s->cap - 1);
+    while (s->slot[h].box != ORC_MISS) {
+        if (s->slot[h].ix == x && s->slot[h].iy == y && s->slot[h].iz == z) return 1;
+        h = (h + 1) & (s->cap - 1);
+    }
+    if (add) { s->slot[h].ix = x; s->slot[h].iy = y; s->slot[h].iz = z; s->slot[h].box = box; s->n++; }
+    return 0;
+}
+static int vcell_cmp(const void *a, const void *b)
+{
+    const vcell *p = (const vcell *)a, *q = (const vcell *)b;
+    if (p->ix != q->ix) return p->ix < q->ix ? -1 : 1;
+    if (p->iy != q->iy) return p->iy < q->iy ? -1 : 1;
+    if (p->iz != q->iz) return p->iz < q->iz ? -1 : 1;
+    return 0;
+}
+static int same_sign(const double a[8])
+{
+    int pflag = 1, nflag = 1;
+    for (int i = 0; i < 8; i++) { if (a[i] > 0) nflag = 0; if (a[i] < 0) pflag = 0; }
+    return pflag || nflag;
+}
+#define ORC_MAX_VOXELS (1u << 24)
+/* ImplicitSurfaceOctree::build, octree.cpp:148-254: find the surface between the two seed points,
+ * put a voxel of half edge min_size around that point and flood-fill over face neighbours whose
+ * eight corner values change sign; every voxel goes into the octree in the set's order. */
+static int implicit_tree_build(otree *t, int kind, double min_size)
+{
+    v3 s0 = V(0, 0, 0), s1 = kind == ORC_OBJ_HEART ? V(2, 0, 0) : V(0, 0.9, 0);   /* Surface.cpp:302, 327-331 */
+    v3 unit = vnorm(vsub(s1, s0));
+    double root;
+    if (single_root(kind, s0, unit, 0, vlen(vsub(s1, s0)), &root)) FAIL("implicit surface: no root between the seed points");
+    v3 midp = vadd(vmul(unit, root), s0);
+    v3 olo = vsub(midp, V(min_size, min_size, min_size)), ohi = vadd(midp, V(min_size, min_size, min_size));
+    const double edge = 2 * min_size;
+    uint64_t cap = 1024, n = 0, head = 0;
+    v3 *lo = (v3 *)malloc(cap * sizeof(v3)), *hi = (v3 *)malloc(cap * sizeof(v3));
+    vset set = { NULL, 0, 0 };
+    lo[0] = olo; hi[0] = ohi; n = 1;
+    vset_find_or_add(&set, 0, 0, 0, 0, 1);
+    v3 blo = V(RT_INFINITE, RT_INFINITE, RT_INFINITE), bhi = V(-RT_INFINITE, -RT_INFINITE, -RT_INFINITE);
+    int rc = 0;
+    while (head < n) {                                  /* boxq is a FIFO: boxes are visited in the order they were found */
+        v3 nlo = lo[head], nhi = hi[head];
+        head++;
+        blo.x = stdmin(blo.x, nlo.x); blo.y = stdmin(blo.y, nlo.y); blo.z = stdmin(blo.z, nlo.z);
+        bhi.x = stdmax(bhi.x, nhi.x); bhi.y = stdmax(bhi.y, nhi.y); bhi.z = stdmax(bhi.z, nhi.z);
+        for (int f = 0; f < 6; f++) {
+            v3 alo, ahi;
+            adj_box(nlo, nhi, f, &alo, &ahi);
+            int64_t ix = llround((alo.x - olo.x) / edge), iy = llround((alo.y - olo.y) / edge), iz = llround((alo.z - olo.z) / edge);
+            if (vset_find_or_add(&set, ix, iy, iz, 0, 0)) continue;
+            double pv[8];
+            for (int i = 0; i < 8; i++) pv[i] = implicit_func(kind, bound_point(i, alo, ahi));
+            if (same_sign(pv)) continue;
+            if (n >= ORC_MAX_VOXELS) { rc = -1; break; }
+            if (n == cap) { cap *= 2; lo = (v3 *)realloc(lo, cap * sizeof(v3)); hi = (v3 *)realloc(hi, cap * sizeof(v3)); }
+            lo[n] = alo; hi[n] = ahi;
+            vset_find_or_add(&set, ix, iy, iz, (uint32_t)n, 1);
+            n++;
+        }
+        if (rc) break;
+    }
+    if (rc) { free(lo); free(hi); free(set.slot); FAIL("implicit surface: too many voxels (min size too small)"); }
+    /* the set's iteration order */
+    vcell *order = (vcell *)malloc(n * sizeof(vcell));
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < set.cap; i++) if (set.slot[i].box != ORC_MISS) order[k++] = set.slot[i];
+    qsort(order, n, sizeof(vcell), vcell_cmp);
+    t->blo = (v3 *)malloc(n * sizeof(v3)); t->bhi = (v3 *)malloc(n * sizeof(v3));
+    for (uint64_t i = 0; i < n; i++) { t->blo[i] = lo[order[i].box]; t->bhi[i] = hi[order[i].box]; }
+    free(order); free(lo); free(hi); free(set.slot);
+    t->boxes = 1; t->ntris = n; t->tris = NULL;
+    t->root = onode_new(blo, bhi, 0);                   /* setBoundBox(box); Octree::build() */
+    for (uint64_t i = 0; i < n; i++) onode_insert(t, t->root, (uint32_t)i);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ scene */
 struct orc_scene {
     orc_object *objects;     uint64_t nobjects;
@@ -467,7 +655,10 @@ struct orc_scene {
     double **tri_store;
     uint32_t *prim_base;     /* global primitive id of each object's first primitive */
     v3 background;
+    otree itree[2];          /* the voxel octree of each implicit kind (HeartShape::ptree is one static tree per class) */
+    int has_itree[2];
 };
+static inline int is_implicit(int type) { return type == ORC_OBJ_HEART || type == ORC_OBJ_GENUS2; }
 
 void orc_scene_destroy(orc_scene *s)
 {
@@ -476,6 +667,11 @@ void orc_scene_destroy(orc_scene *s)
         onode_free(s->trees[i].root);
         free(s->trees[i].blo); free(s->trees[i].bhi);
         free(s->tri_store[i]);
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!s->has_itree[k]) continue;
+        onode_free(s->itree[k].root);
+        free(s->itree[k].blo); free(s->itree[k].bhi);
     }
     free(s->trees); free(s->tri_store); free(s->objects); free(s->materials); free(s->lights);
     free(s->prim_base); free(s);
@@ -532,6 +728,18 @@ orc_scene *orc_scene_create(const orc_scene_desc *d)
         if (o->type == ORC_OBJ_MESH) {
             if (o->mesh < 0 || (uint64_t)o->mesh >= d->nmeshes) { snprintf(g_err, sizeof g_err, "object %d: bad mesh index", (int)i); orc_scene_destroy(s); return NULL; }
             base += (uint32_t)s->trees[o->mesh].ntris;
+        } else if (is_implicit(o->type)) {
+            int k = o->type - ORC_OBJ_HEART;
+            if (!s->has_itree[k]) {
+                otree *t = &s->itree[k];
+                t->max_size = d->octree_max_size > 0 ? d->octree_max_size : 128;
+                t->tol = d->octree_overlap_tol > 0 ? d->octree_overlap_tol : 3;
+                t->max_depth = d->octree_max_depth > 0 ? d->octree_max_depth : 12;
+                if (t->max_depth > OSTACK - 2) t->max_depth = OSTACK - 2;
+                if (implicit_tree_build(t, o->type, d->implicit_min_size > 0 ? d->implicit_min_size : 3e-3)) { orc_scene_destroy(s); return NULL; }
+                s->has_itree[k] = 1;
+            }
+            base += (uint32_t)s->itree[k].ntris;
         } else {
             base += 1;
         }
@@ -559,6 +767,22 @@ int orc_octree_stats(const orc_scene *s, int mesh, uint64_t out[6])
     return 0;
 }
 
+int orc_implicit_stats(const orc_scene *s, int kind, uint64_t out[6])
+{
+    if (!is_implicit(kind) || !s->has_itree[kind - ORC_OBJ_HEART]) FAIL("no implicit surface of that kind in the scene");
+    memset(out, 0, 6 * sizeof(uint64_t));
+    stats_walk(s->itree[kind - ORC_OBJ_HEART].root, out);
+    out[5] = s->itree[kind - ORC_OBJ_HEART].lost;
+    return 0;
+}
+int64_t orc_implicit_boxes(const orc_scene *s, int kind, double *boxes, uint64_t cap)
+{
+    if (!is_implicit(kind) || !s->has_itree[kind - ORC_OBJ_HEART]) FAIL("no implicit surface of that kind in the scene");
+    const otree *t = &s->itree[kind - ORC_OBJ_HEART];
+    for (uint64_t i = 0; i < t->ntris && i < cap; i++) { v3st(boxes + 6 * i, t->blo[i]); v3st(boxes + 6 * i + 3, t->bhi[i]); }
+    return (int64_t)t->ntris;
+}
+
 /* Node::calHit (Surface.h:272-283) for one top-level object, including the normal that
  * Drawable::doAfterHit (Surface.cpp:228-231) stores for every accepted candidate. */
 static int object_calhit(const orc_scene *s, int oi, ray_t r, double t0, double t1, hitrec *rec, counters_t *c)
@@ -566,17 +790,33 @@ static int object_calhit(const orc_scene *s, int oi, ray_t r, double t0, double 
     const orc_object *o = &s->objects[oi];
     double t; uint32_t prim = 0;
     int hit = 0;
+    v3 localp = V(0, 0, 0);
     switch (o->type) {
     case ORC_OBJ_SPHERE: hit = sphere_hit(V(o->p[0], o->p[1], o->p[2]), o->p[3], r, t0, t1, &t); break;
     case ORC_OBJ_GROUND: case ORC_OBJ_WALL_Z: case ORC_OBJ_WALL_X:
         hit = plane_hit(o->type, o->p[0], r, t0, t1, &t); break;
     case ORC_OBJ_MESH: hit = otree_hit(&s->trees[o->mesh], r, t0, t1, &t, &prim, c); break;
+    case ORC_OBJ_HEART: case ORC_OBJ_GENUS2: {
+        /* HeartShape::hit (Surface.cpp:268-276), ImplicitSurface::hit (Surface.h:308-316): the
+         * shared voxel tree is traversed with the ray taken into the surface's frame */
+        ray_t nr;
+        nr.d = vmul(r.d, 1.0 / o->p[3]);
+        nr.e = vmul(vsub(r.e, V(o->p[0], o->p[1], o->p[2])), 1.0 / o->p[3]);
+        hit = otree_hit(&s->itree[o->type - ORC_OBJ_HEART], nr, t0, t1, &t, &prim, c);
+        if (hit) localp = o->type == ORC_OBJ_HEART ? vadd(nr.e, vmul(nr.d, t)) : V(0, 0, 0);   /* Surface.cpp:275 */
+    } break;
     default: break;
     }
     if (!hit) return 0;
+    /* The reference leaves localp untouched for every other drawable, so a record keeps the value
+     * of an earlier, farther HeartShape hit (the record is shared by the Group's children);
+     * here localp always belongs to the accepted hit: zero unless that hit is a HeartShape. */
+    rec->localp = localp;
     rec->t = t; rec->mat = o->material; rec->obj = oi; rec->prim = prim;
     v3 p = vadd(r.e, vmul(r.d, t));
     switch (o->type) {
+    case ORC_OBJ_HEART: case ORC_OBJ_GENUS2:                                                /* Surface.cpp:239-265, Surface.h:301-305 */
+        rec->normal = implicit_normal(o->type, vmul(vsub(p, V(o->p[0], o->p[1], o->p[2])), 1.0 / o->p[3])); break;
     case ORC_OBJ_SPHERE: rec->normal = vnorm(vsub(p, V(o->p[0], o->p[1], o->p[2]))); break; /* Surface.cpp:68-71 */
     case ORC_OBJ_GROUND: rec->normal = V(0, 1, 0); break;                                   /* Surface.h:184 */
     case ORC_OBJ_WALL_Z: rec->normal = V(0, 0, 1); break;                                   /* Surface.h:197 */
@@ -596,6 +836,7 @@ static int group_hit(const orc_scene *s, ray_t r, double t0, double t1, hitrec *
     hitrec tmp;
     hitrec *R = rec ? rec : &tmp;
     int flag = 0;
+    R->localp = V(0, 0, 0);
     if (c) c->rays++;
     for (uint64_t i = 0; i < s->nobjects; i++) {
         if (object_calhit(s, (int)i, r, t0, t1, R, c)) { flag = 1; t1 = R->t; }
@@ -775,7 +1016,11 @@ static v3 ray_color(const pctx *cx, ray_t ray, double t0, double t1, int jumpTim
         if (mat->type & ORC_MAT_NORMAL) {                                /* :307-322 */
             for (uint64_t li = 0; li < s->nlights; li++) {
                 const orc_light *L = &s->lights[li];
-                color = vadd(color, V(L->ambient[0] * mat->ambient[0], L->ambient[1] * mat->ambient[1], L->ambient[2] * mat->ambient[2]));
+                v3 amb = v3p(mat->ambient);
+                if (mat->check == ORC_CHECK_NORMAL) amb = V(fabs(rec.normal.x), fabs(rec.normal.y), fabs(rec.normal.z));           /* material.h:78 */
+                else if (mat->check == ORC_CHECK_POSITION)                                                                        /* material.h:88-89 */
+                    amb = vdivv(vsub(rec.localp, v3p(mat->check_box)), vsub(v3p(mat->check_box + 3), v3p(mat->check_box)));
+                color = vadd(color, V(L->ambient[0] * amb.x, L->ambient[1] * amb.y, L->ambient[2] * amb.z));
                 /* light->getPosition() without a hit record: the point itself, a jittered point of
                  * a FaceLight; a SphereLight would dereference the null record (light.cpp:143) and
                  * is taken at its centre here */

@@ -9,7 +9,8 @@
  * Parity status: the intersection, octree, camera, light-sampling and jitter-table pieces
  * are pinned against the unmodified reference compiled from /root/reference (oracle/_ref,
  * see oracle/Makefile and tests/test_oracle_vs_ref.py) and against the golden vectors in
- * tests/golden/ captured from it.  The integrator (ray_color) is a restatement of
+ * tests/golden/ captured from it; so are the implicit surfaces end to end (voxel set, voxel
+ * octree, BoxNode hits, HeartShape / SurfaceOfGenus2 normals).  The integrator (ray_color) is a restatement of
  * scene.cpp:194-395; scene.cpp itself cannot be compiled here (it includes a Windows-only
  * header through bmpgenerator.h), so ray_color is pinned only through its pinned parts and
  * analytic known-answer scenes: "parity unpinned" for whole-path radiance.
@@ -30,7 +31,11 @@ extern "C" {
 /* material type bits -- material.h:10-16 */
 enum { ORC_MAT_NORMAL = 1, ORC_MAT_SPECULAR = 2, ORC_MAT_TRANSPARENT = 4, ORC_MAT_MONTECARLO = 8 };
 /* object kinds -- Surface.h:50-56 plus the new triangle mesh */
-enum { ORC_OBJ_SPHERE = 1, ORC_OBJ_GROUND = 2, ORC_OBJ_WALL_Z = 3, ORC_OBJ_WALL_X = 4, ORC_OBJ_MESH = 5 };
+enum { ORC_OBJ_SPHERE = 1, ORC_OBJ_GROUND = 2, ORC_OBJ_WALL_Z = 3, ORC_OBJ_WALL_X = 4, ORC_OBJ_MESH = 5,
+       ORC_OBJ_HEART = 6,    /* HeartShape (Surface.h:151-174): p = centre, scale */
+       ORC_OBJ_GENUS2 = 7 }; /* ImplicitSurface<SurfaceOfGenus2Function> (Surface.h:121-147) */
+/* NormalCheckMaterial / PositionCheckMaterial (material.h:70-92): what getAmbient returns */
+enum { ORC_CHECK_NONE = 0, ORC_CHECK_NORMAL = 1, ORC_CHECK_POSITION = 2 };
 enum { ORC_LIGHT_SPHERE = 1, ORC_LIGHT_FACE = 2, ORC_LIGHT_POINT = 3 };
 
 #define ORC_MISS 0xFFFFFFFFu
@@ -45,7 +50,7 @@ typedef struct {
 
 typedef struct {
     int32_t type;      /* ORC_MAT_* bit flags */
-    int32_t reserved;
+    int32_t check;     /* ORC_CHECK_* */
     double  emission[3];
     double  color[3];  /* Material::diffuse == getColor() */
     double  blur;
@@ -53,6 +58,7 @@ typedef struct {
     double  nr;        /* nr_ */
     double  ambient[3], specular[3], mirror[3];   /* Phong branch only (material.h:59-62) */
     double  shine;
+    double  check_box[6];  /* PositionCheckMaterial's box: lo, hi */
 } orc_material;
 
 typedef struct {
@@ -84,6 +90,7 @@ typedef struct {
     int32_t octree_overlap_tol; /* octree.h:26 (3) */
     int32_t octree_max_depth;   /* depth guard, absent in the reference */
     int32_t reserved;
+    double  implicit_min_size;  /* half edge of the implicit surfaces' voxels; 0 = 3e-3 (octree.h:66, Surface.h:123) */
 } orc_scene_desc;
 
 typedef struct {
@@ -116,6 +123,16 @@ const char *orc_last_error(void);
 
 /* out[0..5] = nodes, leaves, object refs, refs held at inner nodes, max depth, lost primitives */
 int orc_octree_stats(const orc_scene *s, int mesh, uint64_t out[6]);
+
+/* The voxel octree shared by the implicit surfaces of one kind (ORC_OBJ_HEART / ORC_OBJ_GENUS2),
+ * ImplicitSurfaceOctree::build (octree.cpp:148-254): stats as above; boxes = the voxels in the
+ * order they are inserted (the std::set order), 6 doubles each (lo, hi); returns their number
+ * (writes at most cap of them) or -1 */
+int orc_implicit_stats(const orc_scene *s, int kind, uint64_t out[6]);
+int64_t orc_implicit_boxes(const orc_scene *s, int kind, double *boxes, uint64_t cap);
+/* the implicit function and the analytic normal of a kind at a point of its own frame */
+double orc_implicit_func(int kind, const double pos[3]);
+void orc_implicit_normal(int kind, const double pos[3], double out[3]);
 
 /* Camera::init, camera.cpp:37-48 */
 void orc_camera_init(const double from[3], const double at[3], const double vup[3],

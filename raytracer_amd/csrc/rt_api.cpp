@@ -46,6 +46,9 @@ struct rt_scene {
     DevScene dev{};
     std::vector<void *> allocs;
     std::vector<MeshInfo> meshes;
+    MeshInfo implicit_info[2];                 // voxel octree per implicit kind
+    std::vector<double> implicit_boxes[2];
+    bool has_implicit[2] = {false, false};
     std::vector<rt_material> materials;
     int nlights = 0;
     int max_push = 1;             // most follow-up rays one shaded hit can append
@@ -160,6 +163,22 @@ int rt_scene_destroy(rt_scene *s)
     return 0;
 }
 
+// Bounding sphere of a voxel record for the same pre-test: the box's centre and half diagonal.
+static LeafSphere make_leaf_sphere(const LeafTri &t);
+static LeafSphere make_voxel_sphere(const LeafTri &t)
+{
+    double c[3], r2 = 0;
+    for (int k = 0; k < 3; k++) { c[k] = (t.v0[k] + t.e1[k]) / 2; const double h = (t.e1[k] - t.v0[k]) / 2; r2 += h * h; }
+    const double r = std::sqrt(r2) * (1.0 + 1e-5) + 4e-7 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
+    LeafSphere s;
+    s.x = (float)c[0]; s.y = (float)c[1]; s.z = (float)c[2];
+    s.r = std::nextafter((float)r, INFINITY);
+    if (!std::isfinite(s.x) || !std::isfinite(s.y) || !std::isfinite(s.z) || !std::isfinite(s.r) || !(r == r)) {
+        s.x = s.y = s.z = 0.0f; s.r = INFINITY;
+    }
+    return s;
+}
+
 // Bounding sphere of the triangle (v0, v0+e1, v0+e2) for the kernels' single-precision
 // pre-test: centre = centroid, radius = largest vertex distance, then inflated by 1e-5 of
 // itself plus 4e-7 of the centre's coordinate magnitudes (the rounding of the centre and of
@@ -237,13 +256,43 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         std::memcpy(infos[mi].stats, ft.stats, sizeof ft.stats);
     }
 
+    // one voxel octree per kind of implicit surface present
+    uint32_t implicit_root[2] = {0, 0};
+    uint64_t implicit_count[2] = {0, 0};
+    MeshInfo implicit_info[2] = {};
+    std::vector<double> implicit_boxes[2];
+    bool has_implicit[2] = {false, false};
+    for (uint64_t i = 0; i < d->nobjects; i++) {
+        const int k = d->objects[i].type - RT_OBJ_HEART;
+        if (k < 0 || k > 1 || has_implicit[k]) continue;
+        FlatTree ft;
+        std::string err;
+        const double min_size = d->implicit_min_size > 0 ? d->implicit_min_size : 3e-3;
+        if (!build_implicit_octree(k, min_size, max_size, tol, max_depth, ft, implicit_boxes[k], err))
+            return fail("rt_scene_create: object " + std::to_string(i) + ": " + err);
+        const uint64_t node_base = nodes.size(), idx_base = leaf_tris.size();
+        if (node_base + ft.nodes.size() >= 0xFFFFFFF0ull || idx_base + ft.leaf_tris.size() >= 0xFFFFFFF0ull)
+            return fail("rt_scene_create: scene too large for 32-bit indices");
+        implicit_root[k] = (uint32_t)node_base;
+        implicit_count[k] = implicit_boxes[k].size() / 6;
+        for (FlatNode f : ft.nodes) {
+            if (f.child_base) f.child_base += (uint32_t)node_base;
+            f.obj_begin += (uint32_t)idx_base;
+            nodes.push_back(f);
+        }
+        leaf_tris.insert(leaf_tris.end(), ft.leaf_tris.begin(), ft.leaf_tris.end());
+        std::memcpy(implicit_info[k].stats, ft.stats, sizeof ft.stats);
+        has_implicit[k] = true;
+    }
+    if (tris.size() / 9 >= (uint64_t)LEAF_VOXEL) return fail("rt_scene_create: too many triangles");
+
     std::vector<DevObject> objs(d->nobjects);
     uint64_t prim = 0;
     for (uint64_t i = 0; i < d->nobjects; i++) {
         const rt_object &o = d->objects[i];
         DevObject &q = objs[i];
         std::memset(&q, 0, sizeof q);
-        if (o.type < RT_OBJ_SPHERE || o.type > RT_OBJ_MESH) return fail("rt_scene_create: object " + std::to_string(i) + " has an unknown type");
+        if (o.type < RT_OBJ_SPHERE || o.type > RT_OBJ_GENUS2) return fail("rt_scene_create: object " + std::to_string(i) + " has an unknown type");
         if (o.material < 0 || (uint64_t)o.material >= d->nmaterials) return fail("rt_scene_create: object " + std::to_string(i) + " has no valid material");
         q.type = o.type; q.material = o.material;
         for (int k = 0; k < 4; k++) q.p[k] = o.p[k];
@@ -257,6 +306,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
             q.leaf_begin = rn.obj_begin;
             for (int k = 0; k < 3; k++) { q.lo[k] = rn.lo[k]; q.hi[k] = rn.hi[k]; }
             prim += mesh_ntris[o.mesh];
+        } else if (o.type == RT_OBJ_HEART || o.type == RT_OBJ_GENUS2) {
+            if (!(o.p[3] != 0.0) || !std::isfinite(o.p[3])) return fail("rt_scene_create: object " + std::to_string(i) + ": implicit surface needs a finite, non-zero scale");
+            q.root = implicit_root[o.type - RT_OBJ_HEART];
+            prim += implicit_count[o.type - RT_OBJ_HEART];
         } else {
             prim += 1;
         }
@@ -274,7 +327,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
     std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
     std::vector<LeafSphere> leaf_sph(leaf_tris.size());
-    for (size_t i = 0; i < leaf_tris.size(); i++) leaf_sph[i] = make_leaf_sphere(leaf_tris[i]);
+    for (size_t i = 0; i < leaf_tris.size(); i++)
+        leaf_sph[i] = (leaf_tris[i].id & LEAF_VOXEL) ? make_voxel_sphere(leaf_tris[i]) : make_leaf_sphere(leaf_tris[i]);
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
     auto up = [&](auto &vec, void **dst) {
         if (e != hipSuccess) return;
@@ -297,13 +351,20 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.regular = 1;
     s->dev.nbig = 0;
     for (const DevObject &q : objs)
-        if (q.type == RT_OBJ_MESH && q.ntri == 0) {
+        if ((q.type == RT_OBJ_MESH && q.ntri == 0) || q.type == RT_OBJ_HEART || q.type == RT_OBJ_GENUS2) {
             // an octree with inner nodes; past RT_MAX_BIG of them the last box grows to hold the rest
             const FlatNode &rn = nodes[q.root];
             const bool fresh = s->dev.nbig < RT_MAX_BIG;
             const int b = fresh ? s->dev.nbig++ : RT_MAX_BIG - 1;
             for (int k = 0; k < 3; k++) {
-                const float lo = std::nextafter((float)rn.lo[k], -INFINITY), hi = std::nextafter((float)rn.hi[k], INFINITY);
+                double wlo = rn.lo[k], whi = rn.hi[k];
+                if (q.type != RT_OBJ_MESH) {
+                    // the voxel tree lives in the surface's own frame: world = centre + scale * local, a little wider
+                    const double a = q.p[k] + q.p[3] * rn.lo[k], c = q.p[k] + q.p[3] * rn.hi[k];
+                    const double m = 1e-6 * (std::fabs(a) + std::fabs(c) + std::fabs(q.p[k]));
+                    wlo = std::fmin(a, c) - m; whi = std::fmax(a, c) + m;
+                }
+                const float lo = std::nextafter((float)wlo, -INFINITY), hi = std::nextafter((float)whi, INFINITY);
                 s->dev.big_lo[b][k] = fresh ? lo : std::fmin(s->dev.big_lo[b][k], lo);
                 s->dev.big_hi[b][k] = fresh ? hi : std::fmax(s->dev.big_hi[b][k], hi);
             }
@@ -315,6 +376,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         }
     for (int k = 0; k < 3; k++) s->dev.background[k] = d->background[k];
     s->meshes = infos;
+    for (int k = 0; k < 2; k++) {
+        s->implicit_info[k] = implicit_info[k];
+        s->implicit_boxes[k].swap(implicit_boxes[k]);
+        s->has_implicit[k] = has_implicit[k];
+    }
     s->materials = mats;
     s->nlights = (int)d->nlights;
     for (const rt_material &m : mats) {
@@ -331,6 +397,25 @@ int rt_scene_octree_stats(const rt_scene *s, int mesh, uint64_t out[6])
     if (mesh < 0 || (size_t)mesh >= s->meshes.size()) return fail("rt_scene_octree_stats: bad mesh index");
     std::memcpy(out, s->meshes[mesh].stats, 6 * sizeof(uint64_t));
     return 0;
+}
+
+int rt_scene_implicit_stats(const rt_scene *s, int kind, uint64_t out[6])
+{
+    if (!s || !out) return fail("rt_scene_implicit_stats: null argument");
+    const int k = kind - RT_OBJ_HEART;
+    if (k < 0 || k > 1 || !s->has_implicit[k]) return fail("rt_scene_implicit_stats: the scene has no implicit surface of that kind");
+    std::memcpy(out, s->implicit_info[k].stats, 6 * sizeof(uint64_t));
+    return 0;
+}
+
+int64_t rt_scene_implicit_boxes(const rt_scene *s, int kind, double *boxes, uint64_t cap)
+{
+    if (!s) return fail("rt_scene_implicit_boxes: null argument");
+    const int k = kind - RT_OBJ_HEART;
+    if (k < 0 || k > 1 || !s->has_implicit[k]) return fail("rt_scene_implicit_boxes: the scene has no implicit surface of that kind");
+    const uint64_t n = s->implicit_boxes[k].size() / 6;
+    if (boxes && cap) std::memcpy(boxes, s->implicit_boxes[k].data(), (size_t)std::min(n, cap) * 6 * sizeof(double));
+    return (int64_t)n;
 }
 
 int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double t1, uint32_t *prim_id, double *t,

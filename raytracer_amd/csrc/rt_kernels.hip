@@ -237,6 +237,8 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 // divisions and the literal comparison forms are used (zero components give the +-inf / NaN
 // cases of hitBox, algorithms.h:208-236).
 enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 5 };
+// flag in TravState::oi while the lane's ray is expressed in an implicit surface's own frame
+#define RT_OI_LOCAL 0x40000000
 // Which kind of step a wave runs next: the one with the largest weighted count of waiting
 // lanes.  Weights are in eighths of a triangle-step lane (triangle steps weigh 8); found by
 // timing, a node step is preferred at 2/3 of the triangle lanes, an object phase needs 4/3.
@@ -318,7 +320,7 @@ __device__ __forceinline__ TriReg tri_load_uniform(u_leaftri p)
 
 template <bool FAST, int BLOCK>
 __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode,
-                                          uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+                                          uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], double *run_bt1, Counters &c)
 {
     const int tid = threadIdx.x;
     const V3 e = T.e, d = T.d, r = T.r;
@@ -416,6 +418,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         T.k = obj_begin; T.kend = obj_begin + obj_count;
         T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
         T.leaf = child_base == 0;
+        run_bt1[tid] = n1;                                  // only voxel records read it back
     }
 }
 
@@ -464,6 +467,20 @@ __device__ __forceinline__ void run_open(const DevScene &S, TravState &T, LeafSp
     for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + (i < last ? i : last));
     T.pend = 0; T.cand = RT_MISS;
 }
+// A voxel of an implicit surface (record with LEAF_VOXEL in its id: v0 / e1 = lower / upper
+// corner, e2x = length of the diagonal).  BoxNode::calHit, Surface.cpp:43-59: the slab test runs
+// on the node's whole window [bt0, bt1], the hit is the entry point moved back along the ray by the
+// diagonal, and OctreeNode::hit keeps it if t <= tempt (octree.cpp:30-33).
+__device__ __forceinline__ void voxel_test(const TriReg &tr, TravState &T, double bt1)
+{
+    const V3 lo = mk(tr.v0x, tr.v0y, tr.v0z), hi = mk(tr.e1x, tr.e1y, tr.e1z);
+    double r0, r1;
+    const bool h = T.fast ? hit_box_fast(lo, hi, T.e, T.d, T.r, T.bt0, bt1, r0, r1) : hit_box(lo, hi, T.e, T.d, T.bt0, bt1, r0, r1);
+    if (h) {
+        const double tt = r0 - tr.e2x / len(T.d);
+        if (tt <= T.tempt) { T.tempt = tt; T.bprim = tr.id & ~LEAF_VOXEL; }
+    }
+}
 __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 {
     double tt;
@@ -473,6 +490,7 @@ __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 // Src supplies the rays of one launch:
 //   uint32_t count() const;
 //   bool load(uint32_t item, V3 &e, V3 &d, double &t0, double &t1) const;  // false: nothing to trace
+//   void reload(uint32_t item, V3 &e, V3 &d) const;                        // the same e, d again
 //   void store(uint32_t item, bool hit, const Hit &h) const;
 // `next` is a zero-initialised device counter shared by the launch; batch_max (a multiple of 64)
 // bounds how many consecutive rays a wave reserves at a time: large batches spare the counter
@@ -487,6 +505,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const int tid = threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
+    __shared__ double run_bt1[BLOCK];        // upper end of the window of the lane's current primitive run
     TravState T = {};
     TriReg R = {};
     LeafSphere Q[4] = {};
@@ -519,6 +538,13 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
         if (mode == TM_FETCH || mode == TM_OBJ) c.rays += 1;
 #endif
         if (mode == TM_OBJ) {
+            if (T.oi & RT_OI_LOCAL) {
+                // back from an implicit surface's voxel tree: the ray returns to the scene's frame
+                T.oi &= ~RT_OI_LOCAL;
+                src.reload(T.item, T.e, T.d);
+                T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
+                T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+            }
             // Octree::hit's verdict (octree.cpp:371-375)
             if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
             T.oi++;
@@ -621,6 +647,20 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                             }
                         }
                     }
+                } else if (otype == RT_OBJ_HEART || otype == RT_OBJ_GENUS2) {
+                    // HeartShape::hit (Surface.cpp:268-276), ImplicitSurface::hit (Surface.h:308-316):
+                    // the voxel tree is traversed with the ray taken into the surface's frame; t is
+                    // the same parameter in both frames.  The lane leaves the sweep here.
+                    if (mine) {
+                        const double inv = 1.0 / objects[o].p[3];
+                        T.e = (T.e - mk(objects[o].p[0], objects[o].p[1], objects[o].p[2])) * inv;
+                        T.d = T.d * inv;
+                        T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
+                        T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                        T.oi = o | RT_OI_LOCAL;
+                        T.root = head.z; T.cur = head.z; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS; mode = TM_NODE;
+                    }
+                    continue;
                 } else if (mine) {
                     const double p0 = objects[o].p[0], p1 = objects[o].p[1], p2 = objects[o].p[2], p3 = objects[o].p[3];
                     double t;
@@ -667,8 +707,8 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     }
                 }
                 const bool in = mode == TM_NODE;
-                if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, c); }
-                else { if (in) node_step<false, BLOCK>(S, T, mode, stk, c); }
+                if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, c); }
+                else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, c); }
                 if (in && mode == TM_TRI) run_open(S, T, Q);
                 RT_TICK(inner)
                 continue;
@@ -686,7 +726,10 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #endif
                 if (mode == TM_TRI) {
                     // 1. the fp64 test of the record requested in the previous step
-                    if (T.cand != RT_MISS) { tri_test(R, T); T.cand = RT_MISS; }
+                    if (T.cand != RT_MISS) {
+                        if (R.id & LEAF_VOXEL) voxel_test(R, T, run_bt1[tid]); else tri_test(R, T);
+                        T.cand = RT_MISS;
+                    }
                     // 2. pre-test the next four records, unless earlier ones still wait for their turn
                     if (T.pend == 0u && T.k < T.kend) {
                         const RayF rf = ray_single(T.e, T.d);
@@ -735,10 +778,31 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 
 // Drawable::doAfterHit -> getRawNormal (Surface.cpp:228-231, 68-71; Surface.h:184,197,211);
 // a mesh hit takes the hit triangle's geometric normal.
+// HeartShape::getRawNormal (Surface.cpp:239-265) and SurfaceOfGenus2Function::getNormal
+// (Surface.cpp:333-343) at a point of the surface's own frame (y and z swapped as there)
+__device__ inline V3 implicit_normal(int type, V3 pos)
+{
+    const double x = pos.x, y = pos.z, z = pos.y;
+    V3 n;
+    if (type == RT_OBJ_HEART) {
+        double temp = x * x + y * y * 9.0 / 4 + z * z - 1;
+        temp = 3 * temp * temp;
+        temp = smax(temp, 0.5);
+        n.x = -2 * x * z * z * z + temp * 2 * x;
+        n.z = -9.0 / 40 * y * z * z * z + temp * 9.0 / 2 * y;
+        n.y = -3 * x * x * z * z - 27.0 / 80 * y * y * z * z + 2 * temp * z;
+    } else {
+        n.x = -12 * x * y * (1 - z * z) + 4 * (x * x + y * y) * x;
+        n.z = 6 * (1 - z * z) * (y * y - x * x) + 4 * (x * x + y * y) * y;
+        n.y = 2 * y * (y * y - 3 * x * x) * -2 * z + 36 * z * z * z - 20 * z;
+    }
+    return norm(n);
+}
 __device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
 {
     const DevObject &o = S.objects[h.obj];
     if (o.type == RT_OBJ_SPHERE) return norm(p - mk(o.p[0], o.p[1], o.p[2]));
+    if (o.type == RT_OBJ_HEART || o.type == RT_OBJ_GENUS2) return implicit_normal(o.type, (p - mk(o.p[0], o.p[1], o.p[2])) * (1.0 / o.p[3]));
     if (o.type == RT_OBJ_GROUND) return mk(0, 1, 0);
     if (o.type == RT_OBJ_WALL_Z) return mk(0, 0, 1);
     if (o.type == RT_OBJ_WALL_X) return mk(1, 0, 0);
@@ -748,6 +812,7 @@ __device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
 __device__ __forceinline__ uint32_t global_prim(const DevScene &S, const Hit &h)
 {
     const DevObject &o = S.objects[h.obj];
+    if (o.type == RT_OBJ_HEART || o.type == RT_OBJ_GENUS2) return o.prim_base + h.prim;      // voxel index
     return o.type == RT_OBJ_MESH ? o.prim_base + (h.prim - o.tri_base) : o.prim_base;
 }
 
@@ -814,6 +879,7 @@ struct RaySrc {             // rt_trace_rays: caller's ray array
     DevScene S; const rt_ray *rays; uint32_t n; double t0, t1; uint32_t *prim_id; double *tout; double *normal;
     __device__ uint32_t count() const { return n; }
     __device__ bool load(uint32_t i, V3 &e, V3 &d, double &a, double &b) const { e = ld3(rays[i].e); d = ld3(rays[i].d); a = t0; b = t1; return true; }
+    __device__ void reload(uint32_t i, V3 &e, V3 &d) const { e = ld3(rays[i].e); d = ld3(rays[i].d); }
     __device__ void store(uint32_t i, bool hit, const Hit &h) const
     {
         prim_id[i] = hit ? global_prim(S, h) : RT_MISS;
@@ -844,6 +910,7 @@ struct PrimarySrc {         // rt_trace_primary: one ray through every pixel cen
         a = 0.0; b = RT_INFINITE;
         return true;
     }
+    __device__ void reload(uint32_t i, V3 &e, V3 &d) const { double a, b; load(i, e, d, a, b); }
     __device__ void store(uint32_t i, bool hit, const Hit &hh) const
     {
         int x, y;
@@ -1052,6 +1119,12 @@ struct StackSrc {
         t1 = ray_f(q, slot, RAY_T1);
         return true;
     }
+    __device__ void reload(uint32_t i, V3 &e, V3 &d) const
+    {
+        const uint64_t slot = base + i;
+        e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
+        d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
+    }
     __device__ void store(uint32_t i, bool hit, const Hit &h) const
     {
         const uint64_t slot = base + i;
@@ -1175,7 +1248,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             }
         } else if (phongN) {                                                 // scene.cpp:307-322
             const rt_light &L = S.lights[li];
-            sum = sum + had(W, had(ld3(L.ambient), ld3(mat.ambient)));
+            V3 amb = ld3(mat.ambient);
+            if (mat.check == RT_CHECK_NORMAL) amb = mk(fabs(normal.x), fabs(normal.y), fabs(normal.z));              // material.h:78
+            else if (mat.check == RT_CHECK_POSITION) {                                                                // material.h:88-89
+                // HitRecord::localp: the hit in a HeartShape's own frame (Surface.cpp:268-275), zero for any other drawable
+                const DevObject &ho = S.objects[h.obj];
+                V3 lp = mk(0, 0, 0);
+                if (ho.type == RT_OBJ_HEART) {
+                    const double inv = 1.0 / ho.p[3];
+                    lp = (re - mk(ho.p[0], ho.p[1], ho.p[2])) * inv + (rd * inv) * ht;
+                }
+                const V3 blo = ld3(mat.check_box), bhi = ld3(mat.check_box + 3);
+                amb = mk((lp.x - blo.x) / (bhi.x - blo.x), (lp.y - blo.y) / (bhi.y - blo.y), (lp.z - blo.z) / (bhi.z - blo.z));
+            }
+            sum = sum + had(W, had(ld3(L.ambient), amb));
             // light->getPosition() without a hit record: the point itself, a jittered point of a
             // FaceLight; a SphereLight (which would dereference the null record, light.cpp:143) is
             // taken at its centre

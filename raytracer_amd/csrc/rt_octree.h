@@ -30,6 +30,9 @@ struct LeafTri {
     uint32_t id;      // triangle index (within the mesh at build time)
     uint32_t pad;
 };
+// A voxel of an implicit surface uses the same record: v0 / e1 = lower / upper corner, e2[0] =
+// length of its diagonal, id = voxel index | LEAF_VOXEL.
+enum : uint32_t { LEAF_VOXEL = 0x80000000u };
 static_assert(sizeof(LeafTri) == 80, "LeafTri must be 80 bytes");
 
 struct FlatTree {
@@ -45,5 +48,12 @@ struct FlatTree {
 // (octree.cpp:207-212, 248).
 bool build_octree(const double *tris, uint64_t ntris, double pad, int max_size, int overlap_tol,
                   int max_depth, FlatTree &out, std::string &err);
+
+// The voxel octree of an implicit surface (kind 0: heart, 1: genus-2 surface), as
+// ImplicitSurfaceOctree::build (octree.cpp:148-254) makes it; `boxes` receives the voxels in
+// insertion order (6 doubles each: lower corner, upper corner).
+bool build_implicit_octree(int kind, double min_size, int max_size, int overlap_tol, int max_depth,
+                           FlatTree &out, std::vector<double> &boxes, std::string &err);
+double implicit_value(int kind, const double pos[3]);
 
 } // namespace rt

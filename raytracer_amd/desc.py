@@ -15,8 +15,11 @@ import numpy as np
 
 # material type bits -- material.h:10-16
 MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MAT_MONTECARLO = 1, 2, 4, 8
-# object kinds -- Surface.h:50-56 (+ the triangle mesh this build adds)
-OBJ_SPHERE, OBJ_GROUND, OBJ_WALL_Z, OBJ_WALL_X, OBJ_MESH = 1, 2, 3, 4, 5
+# object kinds -- Surface.h:50-56 (+ the triangle mesh this build adds, + the implicit surfaces
+# HeartShape, Surface.h:151-174, and SurfaceOfGenus2, Surface.h:121-147: p = centre, scale)
+OBJ_SPHERE, OBJ_GROUND, OBJ_WALL_Z, OBJ_WALL_X, OBJ_MESH, OBJ_HEART, OBJ_GENUS2 = 1, 2, 3, 4, 5, 6, 7
+# NormalCheckMaterial / PositionCheckMaterial (material.h:70-92)
+CHECK_NONE, CHECK_NORMAL, CHECK_POSITION = 0, 1, 2
 LIGHT_SPHERE, LIGHT_FACE, LIGHT_POINT = 1, 2, 3
 MISS = 0xFFFFFFFF
 
@@ -26,17 +29,18 @@ PI = 3.1415926    # definitions.h:7 (7 digits, kept on purpose)
 
 OBJECT_DT = np.dtype([("type", "<i4"), ("material", "<i4"), ("mesh", "<i4"), ("reserved", "<i4"),
                       ("p", "<f8", (4,))], align=True)
-MATERIAL_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("emission", "<f8", (3,)),
+MATERIAL_DT = np.dtype([("type", "<i4"), ("check", "<i4"), ("emission", "<f8", (3,)),
                         ("color", "<f8", (3,)), ("blur", "<f8"), ("atten", "<f8", (3,)),
                         ("nr", "<f8"), ("ambient", "<f8", (3,)), ("specular", "<f8", (3,)),
-                        ("mirror", "<f8", (3,)), ("shine", "<f8")], align=True)
+                        ("mirror", "<f8", (3,)), ("shine", "<f8"), ("check_box", "<f8", (6,))],
+                       align=True)
 LIGHT_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("pos", "<f8", (3,)), ("radius", "<f8"),
                      ("normal", "<f8", (3,)), ("up", "<f8", (3,)), ("right", "<f8", (3,)),
                      ("width", "<f8"), ("height", "<f8"), ("diffuse", "<f8", (3,)),
                      ("ambient", "<f8", (3,)), ("specular", "<f8", (3,))], align=True)
 RAY_DT = np.dtype([("e", "<f8", (3,)), ("d", "<f8", (3,))], align=True)
 
-assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 176 and LIGHT_DT.itemsize == 200
+assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 224 and LIGHT_DT.itemsize == 200
 
 
 class MeshC(C.Structure):
@@ -51,7 +55,8 @@ class SceneDescC(C.Structure):
                 ("background", C.c_double * 3),
                 ("tri_box_pad", C.c_double),
                 ("octree_max_size", C.c_int32), ("octree_overlap_tol", C.c_int32),
-                ("octree_max_depth", C.c_int32), ("reserved", C.c_int32)]
+                ("octree_max_depth", C.c_int32), ("reserved", C.c_int32),
+                ("implicit_min_size", C.c_double)]
 
 
 class CameraC(C.Structure):
@@ -71,7 +76,8 @@ class SceneDesc:
     """A flattened scene: objects in Group child order, materials, lights, triangle meshes."""
 
     def __init__(self, objects, materials, lights, meshes, background=(0.0, 0.0, 0.0),
-                 tri_box_pad=1e-7, octree_max_size=128, octree_overlap_tol=3, octree_max_depth=12):
+                 tri_box_pad=1e-7, octree_max_size=128, octree_overlap_tol=3, octree_max_depth=12,
+                 implicit_min_size=0.0):
         self.objects = np.ascontiguousarray(objects, dtype=OBJECT_DT)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DT)
         self.lights = np.ascontiguousarray(lights, dtype=LIGHT_DT)
@@ -81,6 +87,7 @@ class SceneDesc:
         self.octree_max_size = int(octree_max_size)
         self.octree_overlap_tol = int(octree_overlap_tol)
         self.octree_max_depth = int(octree_max_depth)
+        self.implicit_min_size = float(implicit_min_size)   # 0 = the reference's 3e-3
 
     def to_c(self):
         """Return (SceneDescC, keepalive) -- keepalive must outlive the call that reads it."""
@@ -98,14 +105,19 @@ class SceneDesc:
         d.octree_max_size = self.octree_max_size
         d.octree_overlap_tol = self.octree_overlap_tol
         d.octree_max_depth = self.octree_max_depth
+        d.implicit_min_size = self.implicit_min_size
         return d, (mesh_arr, self)
 
     @property
     def prim_base(self):
-        """Global primitive id of each object's first primitive (mesh: one id per triangle)."""
+        """Global primitive id of each object's first primitive (mesh: one id per triangle).
+        Scenes with implicit surfaces have one id per voxel; their count is only known to the
+        library that built the voxels, so this helper refuses them."""
         base, out = 0, []
         for o in self.objects:
             out.append(base)
+            if int(o["type"]) in (OBJ_HEART, OBJ_GENUS2):
+                raise ValueError("prim_base: the scene holds implicit surfaces")
             base += self.meshes[int(o["mesh"])].shape[0] if int(o["type"]) == OBJ_MESH else 1
         return np.asarray(out + [base], dtype=np.int64)
 

@@ -22,6 +22,7 @@ EXPORTS = (
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
+    "rt_scene_implicit_stats", "rt_scene_implicit_boxes",
 )
 
 _lib = None
@@ -65,6 +66,9 @@ def lib():
     L.rt_camera_change_fov.argtypes = [C.POINTER(CameraC), _dbl, C.POINTER(CameraC)]
     L.rt_light_move_face.argtypes = [_vp, _dbl, _vp]
     L.rt_scene_set_light.argtypes = [_vp, _u64, _vp, _vp]
+    L.rt_scene_implicit_stats.argtypes = [_vp, _int, C.POINTER(C.c_uint64)]
+    L.rt_scene_implicit_boxes.restype = C.c_int64
+    L.rt_scene_implicit_boxes.argtypes = [_vp, _int, _vp, _u64]
     _lib = L
     return L
 
@@ -209,6 +213,20 @@ class HipScene:
         out = (C.c_double * 6)()
         _chk(lib().rt_scene_get_profile(self._h, out, 1 if reset else 0), "rt_scene_get_profile")
         return dict(zip(("trace_launches", "trace_ms", "shade_launches", "shade_ms", "generate_launches", "rounds"), out[:]))
+
+    def implicit_stats(self, kind):
+        out = (C.c_uint64 * 6)()
+        _chk(lib().rt_scene_implicit_stats(self._h, kind, out), "rt_scene_implicit_stats")
+        return dict(zip(("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost"), [int(x) for x in out]))
+
+    def implicit_boxes(self, kind):
+        """The voxels of the scene's implicit surfaces of `kind`, in insertion order: (n, 6)."""
+        n = lib().rt_scene_implicit_boxes(self._h, kind, None, 0)
+        if n < 0:
+            _chk(-1, "rt_scene_implicit_boxes")
+        out = np.empty((n, 6), np.float64)
+        lib().rt_scene_implicit_boxes(self._h, kind, _p(out), n)
+        return out
 
     def set_light(self, index, light, stream=0):
         """Replace light `index` (a LIGHT_DT record) of the uploaded scene."""

@@ -10,8 +10,8 @@ import math
 import numpy as np
 
 from .desc import (LIGHT_DT, LIGHT_FACE, LIGHT_POINT, LIGHT_SPHERE, MAT_MONTECARLO, MAT_NORMAL, MAT_SPECULAR,
-                   MAT_TRANSPARENT, MATERIAL_DT, OBJ_GROUND, OBJ_MESH, OBJ_SPHERE, OBJ_WALL_X, OBJ_WALL_Z,
-                   OBJECT_DT, SceneDesc)
+                   MAT_TRANSPARENT, MATERIAL_DT, OBJ_GENUS2, OBJ_GROUND, OBJ_HEART, OBJ_MESH, OBJ_SPHERE,
+                   OBJ_WALL_X, OBJ_WALL_Z, OBJECT_DT, CHECK_NORMAL, CHECK_POSITION, SceneDesc)
 
 
 # ----------------------------------------------------------------------------- record helpers
@@ -395,4 +395,63 @@ def kaleidoscope_scene(width=1020, height=630):
         objs.append(sphere(pos, R, 2 + i))
     desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [], background=(0, 0, 0))
     cam = dict(look_from=(50, 40, -120), look_at=(50, 40, Z), vup=(0, 1, 0), vfov=95.0, aspect=width * 1.0 / height)
+    return desc, cam
+
+
+def implicit_object(kind, center, scale, mat):
+    """HeartShape(center, scale) / SurfaceOfGenus2(center, scale) -- Surface.h:151-174, 131-147."""
+    o = np.zeros((), OBJECT_DT)
+    o["type"], o["material"], o["mesh"] = kind, mat, -1
+    o["p"] = (center[0], center[1], center[2], scale)
+    return o
+
+
+def check_material(kind, box=None):
+    """NormalCheckMaterial() / PositionCheckMaterial(box) -- material.h:70-92: Phong materials with
+    black colours whose ambient term shows |normal| or the hit's position inside `box`."""
+    m = phong_material((0, 0, 0), (0, 0, 0), (0, 0, 0), 1.0)
+    m["check"] = kind
+    if box is not None:
+        m["check_box"] = tuple(box[0]) + tuple(box[1])
+    return m
+
+
+def implicit_scene(variant="montecarlo", min_size=1e-2):
+    """Implicit surfaces through their voxel octrees (HeartShape, SurfaceOfGenus2): two hearts
+    (one tree, two placements) and a genus-2 surface on a ground plane in front of two walls.
+    variant "montecarlo": diffuse / mirror Monte-Carlo materials under a FaceLight;
+    variant "check": the reference's NormalCheck / PositionCheck materials and a Phong material
+    under a point Light (the reference's debug view of an implicit surface)."""
+    if variant == "montecarlo":
+        mats = [material(MAT_NORMAL | MAT_MONTECARLO, color=(.75, .25, .25)),
+                material(MAT_SPECULAR | MAT_MONTECARLO, color=(.9, .9, .9)),
+                material(MAT_NORMAL | MAT_MONTECARLO, color=(.3, .6, .35)),
+                material(MAT_NORMAL | MAT_MONTECARLO, color=(.7, .7, .7))]
+        lights = [face_light((0, 5.5, 2), (0, -1, 0), (0, 0, 1), 3.0, 3.0, (14, 14, 13))]
+    else:
+        mats = [check_material(CHECK_NORMAL), check_material(CHECK_POSITION, ((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5))),
+                phong_material((.05, .08, .05), (.3, .6, .35), (.4, .4, .4), 20.0, mirror=(.3, .3, .3)),
+                phong_material((.06, .06, .06), (.6, .6, .6), (.1, .1, .1), 4.0)]
+        lights = [point_light((3, 7, 6), (1, 1, 1), (.9, .9, .8), (1, 1, 1))]
+    objs = [implicit_object(OBJ_HEART, (-1.6, 1.6, 0.2), 1.1, 0), implicit_object(OBJ_HEART, (1.9, 1.2, -0.6), 0.8, 1),
+            implicit_object(OBJ_GENUS2, (0.3, 1.1, 1.8), 0.9, 2),
+            plane(OBJ_GROUND, 0.0, 3), plane(OBJ_WALL_Z, -3.5, 3), plane(OBJ_WALL_X, -5.0, 3)]
+    desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [],
+                     background=(0.06, 0.07, 0.1), implicit_min_size=min_size)
+    cam = dict(look_from=(0.6, 3.0, 8.5), look_at=(0.1, 1.3, 0), vup=(0, 1, 0), vfov=40.0, aspect=4 / 3)
+    return desc, cam
+
+
+def heart_example_scene(width=320, height=240, min_size=1e-2):
+    """The scene of examples/main_heart.cpp."""
+    mats = [check_material(CHECK_NORMAL), material(MAT_NORMAL, color=(.75, .25, .25)),
+            phong_material((.05, .08, .05), (.3, .6, .35), (.4, .4, .4), 20.0, mirror=(.3, .3, .3)),
+            phong_material((.06, .06, .06), (.6, .6, .6), (.1, .1, .1), 4.0)]
+    objs = [implicit_object(OBJ_HEART, (-1.6, 1.6, 0.2), 1.1, 0), implicit_object(OBJ_HEART, (1.9, 1.2, -0.6), 0.8, 1),
+            implicit_object(OBJ_GENUS2, (0.3, 1.1, 1.8), 0.9, 2), plane(OBJ_GROUND, 0.0, 3), plane(OBJ_WALL_Z, -3.5, 3)]
+    lights = [point_light((3, 7, 6), (1, 1, 1), (.9, .9, .8), (1, 1, 1)),
+              face_light((0, 5.5, 2), (0, -1, 0), (0, 0, 1), 3.0, 3.0, (.6, .6, .55), ambient=(.1, .1, .1), specular=(.3, .3, .3))]
+    desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [],
+                     background=(0.06, 0.07, 0.1), implicit_min_size=min_size)
+    cam = dict(look_from=(0.6, 3.0, 8.5), look_at=(0.1, 1.3, 0), vup=(0, 1, 0), vfov=40.0, aspect=width * 1.0 / height)
     return desc, cam

@@ -35,6 +35,17 @@ def rand_rays(rng, n, lo=-1.0, hi=2.0, axis_frac=0.05):
     return r
 
 
+def shell_rays(rng, n, radius, target):
+    """Rays from a shell of the given radius around the origin towards a small ball at its centre."""
+    r = np.zeros(n, RAY_DT)
+    e = rng.normal(size=(n, 3)); e *= radius / np.linalg.norm(e, axis=1, keepdims=True)
+    d = rng.uniform(-target, target, (n, 3)) - e
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::17, 0] = 0.0
+    r["e"], r["d"] = e, d
+    return r
+
+
 def main():
     assert orc.ref_available(), "build oracle/_ref first (make -C oracle)"
     rng = np.random.default_rng(20260101)
@@ -130,6 +141,29 @@ def main():
     rays["d"] = (rng.uniform(-2.5, 2.5, (5000, 3)) + np.array([0, 1, 0])) - rays["e"]
     which, t, nrm = orc.ref_group_hit(objs, rays, 1e-9, 1e10)
     np.savez_compressed(os.path.join(HERE, "group_hit.npz"), e=rays["e"], d=rays["d"], which=which, t=t, normal=nrm)
+    # 8. implicit surfaces: the reference's voxel octree (ImplicitSurfaceOctree::build, octree.cpp:148-254;
+    #    BoxNode::calHit, Surface.cpp:43-59) and the drawables HeartShape / SurfaceOfGenus2 through
+    #    Node::calHit at the reference's default voxel size (normals, localp)
+    out = {}
+    for kind, min_size in ((6, 2e-2), (7, 1.5e-2)):
+        tree = orc.RefImplicit(kind, min_size)
+        st_ = tree.stats()
+        boxes = tree.boxes()
+        rr = np.random.default_rng(100 + kind)
+        rays = np.concatenate([shell_rays(rr, 5000, 4.0, 0.8), shell_rays(rr, 1500, 0.3, 2.0)])
+        h1, t1 = tree.hit(rays, 0.0, 1e10)
+        h2, t2 = tree.hit(rays, 1e-9, 3.6)
+        k = f"k{kind}_"
+        out.update({k + "min_size": min_size, k + "stats": np.array([st_[x] for x in ("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost")]),
+                    k + "nbox": len(boxes), k + "boxes_every_16th": boxes[::16].copy(), k + "box_sum": boxes.sum(axis=0),
+                    k + "e": rays["e"], k + "d": rays["d"], k + "hit": h1, k + "t": t1, k + "hit_clip": h2, k + "t_clip": t2})
+        center, scale = (0.4, -0.3, 1.1), 1.7
+        rays = shell_rays(rr, 2500, 7.0, 1.2)
+        rays["e"] += center
+        h, t, nrm, lp = orc.ref_implicit_object_hit(kind, center, scale, rays, 0.0, 1e10)
+        out.update({k + "center": np.array(center), k + "scale": scale, k + "obj_e": rays["e"], k + "obj_d": rays["d"],
+                    k + "obj_hit": h, k + "obj_t": t, k + "obj_normal": nrm, k + "obj_localp": lp})
+    np.savez_compressed(os.path.join(HERE, "implicit.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -136,3 +136,33 @@ def test_group_hit_bit_exact(golden_dir):
     hit = which >= 0
     assert np.array_equal(t[hit], g["t"][hit]) and np.array_equal(nrm[hit], g["normal"][hit])
     assert hit.sum() > 500
+
+
+def _implicit_desc(kind, center=(0, 0, 0), scale=1.0, min_size=0.0):
+    return SceneDesc(scenes._stack([scenes.implicit_object(kind, center, scale, 0)], OBJECT_DT),
+                     scenes._stack([scenes.phong_material((.1, .1, .1), (.6, .3, .3), (.4, .4, .4), 16.0)], MATERIAL_DT),
+                     np.zeros(0, LIGHT_DT), [], implicit_min_size=min_size, octree_max_depth=15)
+
+
+@pytest.mark.parametrize("kind", [6, 7])
+def test_implicit_surfaces_bit_exact(golden_dir, kind):
+    """Voxelisation, voxel octree and BoxNode hits of the reference's implicit surfaces, then the
+    drawables (frame change, analytic normals) at the reference's default voxel size."""
+    g = _load(golden_dir, "implicit")
+    k = f"k{kind}_"
+    s = orc.OracleScene(_implicit_desc(kind, min_size=float(g[k + "min_size"])))
+    st = s.implicit_stats(kind)
+    assert [st[x] for x in ("nodes", "leaves", "refs", "inner_refs", "max_depth", "lost")] == list(g[k + "stats"])
+    boxes = s.implicit_boxes(kind)
+    assert len(boxes) == int(g[k + "nbox"]) and np.array_equal(boxes[::16], g[k + "boxes_every_16th"])
+    assert np.array_equal(boxes.sum(axis=0), g[k + "box_sum"])
+    rays = np.zeros(len(g[k + "e"]), RAY_DT); rays["e"] = g[k + "e"]; rays["d"] = g[k + "d"]
+    prim, t, _, _ = s.trace_rays(rays, 0.0, 1e10)
+    assert np.array_equal(prim != MISS, g[k + "hit"] != 0) and np.array_equal(t, g[k + "t"])
+    prim, t, _, _ = s.trace_rays(rays, 1e-9, 3.6)
+    assert np.array_equal(prim != MISS, g[k + "hit_clip"] != 0) and np.array_equal(t, g[k + "t_clip"])
+    s = orc.OracleScene(_implicit_desc(kind, tuple(g[k + "center"]), float(g[k + "scale"])))
+    rays = np.zeros(len(g[k + "obj_e"]), RAY_DT); rays["e"] = g[k + "obj_e"]; rays["d"] = g[k + "obj_d"]
+    prim, t, nrm, _ = s.trace_rays(rays, 0.0, 1e10)
+    assert np.array_equal(prim != MISS, g[k + "obj_hit"] != 0) and np.array_equal(t, g[k + "obj_t"])
+    assert np.array_equal(nrm, g[k + "obj_normal"]) and (g[k + "obj_hit"] != 0).sum() > 200
