@@ -35,6 +35,10 @@ enum { RT_OBJ_SPHERE = 1, RT_OBJ_GROUND = 2, RT_OBJ_WALL_Z = 3, RT_OBJ_WALL_X = 
 /* NormalCheckMaterial / PositionCheckMaterial (material.h:70-92): getAmbient() returns |normal|,
  * or the hit's local position relative to check_box, instead of the stored ambient colour */
 enum { RT_CHECK_NONE = 0, RT_CHECK_NORMAL = 1, RT_CHECK_POSITION = 2 };
+/* PerlinNoiseNormalMaterial / PerlinNoiseNormalMaterial_Blood (material.h:95-164): Phong
+ * materials whose colours follow Perlin noise at the hit position (the _Blood variant also mixes
+ * in a vein colour and tilts the normal, material.cpp:67-87) */
+enum { RT_PERLIN_NONE = 0, RT_PERLIN_NORMAL = 1, RT_PERLIN_BLOOD = 2 };
 /* SphereLight / FaceLight / the point Light -- light.h:8-73 */
 enum { RT_LIGHT_SPHERE = 1, RT_LIGHT_FACE = 2, RT_LIGHT_POINT = 3 };
 
@@ -66,6 +70,9 @@ typedef struct {
     double  mirror[3];   /* getMirror() */
     double  shine;       /* getShine() */
     double  check_box[6];/* PositionCheckMaterial(box): lower corner, upper corner */
+    int32_t perlin;      /* RT_PERLIN_* */
+    int32_t reserved;
+    double  perlin_scale;/* scale_ (material.h:97-99) */
 } rt_material;
 
 /* SphereLight(pos, radius, emission) light.cpp:109-116 ; FaceLight(...) light.cpp:50-56 ;
@@ -104,6 +111,12 @@ typedef struct {
     int32_t reserved;
     double  implicit_min_size;  /* half edge of an implicit surface's voxels; 0 = 3e-3, the value both reference
                                    surfaces use (octree.h:66, Surface.h:123) */
+    const int32_t *perlin_p;    /* PerlinNoiseGenerator::P_ (permutation, perlin_n entries) and */
+    const double  *perlin_g;    /* G_ (unit vectors, 3 x perlin_n); NULL = rt_perlin_tables(12325, 256, ..),
+                                   the generator's own SEED and size (algorithms.h:91,99).  The animation of
+                                   G_ by PerlinNoiseGeneratorWithTime::timeChanged is the caller's to apply. */
+    int32_t perlin_n;
+    int32_t reserved2;
 } rt_scene_desc;
 
 /* Camera members after Camera::init -- camera.cpp:37-48 */
@@ -152,6 +165,12 @@ int rt_scene_octree_stats(const rt_scene *scene, int mesh, uint64_t out[6]);
  * (writing at most `cap` of them) or a negative error. */
 int rt_scene_implicit_stats(const rt_scene *scene, int kind, uint64_t out[6]);
 int64_t rt_scene_implicit_boxes(const rt_scene *scene, int kind, double *boxes, uint64_t cap);
+
+/* PerlinNoiseGenerator::PerlinNoiseGenerator (algorithms.cpp:4-19) replayed on the host with the
+ * generator it was written for (MSVC's rand(): s = s*214013 + 2531011, (s >> 16) & 0x7fff):
+ * P[n], G[3n].  algorithm::perlinNoise (algorithms.h:56-87) over given tables, host arithmetic. */
+int rt_perlin_tables(uint32_t seed, int n, int32_t *P, double *G);
+double rt_perlin_noise(double x, double y, double z, double scale, const int32_t *P, const double *G, int n);
 
 /* Camera::Camera -> init, camera.cpp:5-8,37-48 (host arithmetic) */
 int rt_camera_init(const double look_from[3], const double look_at[3], const double vup[3],

@@ -82,6 +82,7 @@ public:
     void setMirrorBlur(double b) { rec_.blur = b; }
 protected:
     void setCheck(int kind) { rec_.check = kind; }
+    void setPerlin(int kind, double scale) { rec_.perlin = kind; rec_.perlin_scale = scale; }
     void setCheckBox(const Vec3 &lo, const Vec3 &hi)
     {
         rec_.check_box[0] = lo.x_; rec_.check_box[1] = lo.y_; rec_.check_box[2] = lo.z_;
@@ -106,6 +107,19 @@ public:
     {
         setCheck(RT_CHECK_POSITION); setCheckBox(lo, hi);
     }
+};
+
+// material.h:95-164: Phong materials modulated by Perlin noise at the hit position
+class PerlinNoiseNormalMaterial : public Material {
+public:
+    PerlinNoiseNormalMaterial(Color amb, Color dif, Color spe, double shi, double scale = 1) : Material(amb, dif, spe, shi) { setPerlin(RT_PERLIN_NORMAL, scale); }
+protected:
+    PerlinNoiseNormalMaterial(Color amb, Color dif, Color spe, double shi, double scale, int kind) : Material(amb, dif, spe, shi) { setPerlin(kind, scale); }
+};
+class PerlinNoiseNormalMaterial_Blood : public PerlinNoiseNormalMaterial {
+public:
+    PerlinNoiseNormalMaterial_Blood(Color amb, Color dif, Color spe, double shi, double scale = 1)
+        : PerlinNoiseNormalMaterial(amb, dif, spe, shi, scale, RT_PERLIN_BLOOD) {}
 };
 
 // Surface.h:47-74

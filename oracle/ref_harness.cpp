@@ -372,6 +372,50 @@ void ref_implicit_object_hit(int kind, const double center[3], double scale, con
     }
 }
 
+// ---- Perlin noise and the Perlin materials (algorithms.h:56-111, algorithms.cpp:2-40,
+// material.h:95-164, material.cpp:67-87)
+double ref_perlin_noise(double x, double y, double z, double scale, const int32_t *P, const double *G, int n)
+{
+    std::vector<int> p(P, P + n);
+    std::vector<Vec3> g;
+    for (int i = 0; i < n; i++) g.push_back(Vec3(G[3 * i], G[3 * i + 1], G[3 * i + 2]));
+    return algorithm::perlinNoise(x, y, z, scale, p, g, n);
+}
+// The generator's tables as its constructor fills them HERE (glibc rand(); the reference was
+// written for MSVC's generator, so these are test data, not the Windows tables)
+void ref_perlin_tables(int n, int32_t *P, double *G)
+{
+    algorithm::PerlinNoiseGenerator::P_.clear();
+    algorithm::PerlinNoiseGenerator::G_.clear();
+    algorithm::PerlinNoiseGenerator gen(n);
+    for (int i = 0; i < n; i++) {
+        P[i] = algorithm::PerlinNoiseGenerator::P_[i];
+        st(G + 3 * i, algorithm::PerlinNoiseGenerator::G_[i]);
+    }
+}
+// kind 1: PerlinNoiseNormalMaterial, 2: PerlinNoiseNormalMaterial_Blood, with the generator's
+// static tables set to P, G.  out = getAmbient, getDiffuse, getSpecular, getNormal(normal)
+// after setPosition(pos) (12 doubles).
+void ref_perlin_material(int kind, const double amb[3], const double dif[3], const double spe[3], double shine, double scale,
+                         const int32_t *P, const double *G, int n, const double pos[3], const double normal[3], double out[12])
+{
+    std::shared_ptr<PerlinNoiseNormalMaterial> m;
+    Color a(amb[0], amb[1], amb[2], 1), d(dif[0], dif[1], dif[2], 1), sp(spe[0], spe[1], spe[2], 1);
+    if (kind == 1) m = std::make_shared<PerlinNoiseNormalMaterial>(a, d, sp, shine, scale);
+    else m = std::make_shared<PerlinNoiseNormalMaterial_Blood>(a, d, sp, shine, scale);
+    algorithm::PerlinNoiseGenerator::P_.assign(P, P + n);
+    algorithm::PerlinNoiseGenerator::G_.clear();
+    for (int i = 0; i < n; i++) algorithm::PerlinNoiseGenerator::G_.push_back(Vec3(G[3 * i], G[3 * i + 1], G[3 * i + 2]));
+    m->setPosition(v3(pos));
+    HitRecord rec;
+    Color ca = m->getAmbient(&rec), cd = m->getDiffuse(&rec), cs = m->getSpecular(&rec);
+    Vec3 nn = m->getNormal(v3(normal));
+    out[0] = ca.x_; out[1] = ca.y_; out[2] = ca.z_;
+    out[3] = cd.x_; out[4] = cd.y_; out[5] = cd.z_;
+    out[6] = cs.x_; out[7] = cs.y_; out[8] = cs.z_;
+    st(out + 9, nn);
+}
+
 // RTObject::calRandom structure check (RTObject.cpp:46-69) cannot be run on glibc
 // (RAND_MAX + 1 overflows); only the table layout constants are exposed.
 double ref_const_zero(void) { return ZERO; }

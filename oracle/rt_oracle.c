@@ -646,6 +646,110 @@ static int implicit_tree_build(otree *t, int kind, double min_size)
     return 0;
 }
 
+/* ------------------------------------------------------------------ Perlin materials */
+typedef struct { const int32_t *P; const double *G; int n; } perlin_t;
+static inline int perlin_fai(const perlin_t *t, int v)
+{
+    int m = v % t->n;
+    return t->P[m >= 0 ? m : t->n + m];
+}
+static inline double perlin_weight(double t)
+{
+    double at = fabs(t);
+    if (at < 1) return 2 * at * at * at - 3 * at * at + 1;
+    return 0.0;
+}
+/* algorithm::perlinNoise, algorithms.h:56-87 */
+static double perlin_noise(const perlin_t *t, double x, double y, double z, double scale)
+{
+    x /= scale; y /= scale; z /= scale;
+    double result = 0;
+    for (int n = 0; n < 8; n++) {
+        int i = (n & 0x01) ? floor(x) : floor(x) + 1;
+        int j = (n & 0x02) ? floor(y) : floor(y) + 1;
+        int k = (n & 0x04) ? floor(z) : floor(z) + 1;
+        double u = x - i, v = y - j, w = z - k;
+        const double *g = t->G + 3 * perlin_fai(t, i + perlin_fai(t, j + perlin_fai(t, k)));
+        result += perlin_weight(u) * perlin_weight(v) * perlin_weight(w) * (g[0] * u + g[1] * v + g[2] * w);
+    }
+    return result;
+}
+double orc_perlin_noise(double x, double y, double z, double scale, const int32_t *P, const double *G, int n)
+{
+    perlin_t t = { P, G, n };
+    return perlin_noise(&t, x, y, z, scale);
+}
+static inline double perlin_normalized(const perlin_t *t, v3 p, double scale) { return perlin_noise(t, p.x, p.y, p.z, scale) / 2 + 0.5; }          /* algorithms.cpp:37-40 */
+static inline double perlin_line(const perlin_t *t, v3 p, double scale) { return stdmin(fabs(perlin_noise(t, p.x, p.y, p.z, scale)) * 11, 1.0); }   /* algorithms.cpp:32-35 */
+
+void orc_perlin_tables(uint32_t seed, int n, int32_t *P, double *G)
+{
+    uint32_t st = seed;                                    /* srand(SEED), algorithms.cpp:7 */
+#define MSRAND() (st = st * 214013u + 2531011u, (int)((st >> 16) & 0x7fff))
+    for (int i = 0; i < n; i++) {                          /* genRandomUnitVec, algorithms.h:37-46: keeps points OUTSIDE the unit ball */
+        v3 a;
+        do {
+            a.x = MSRAND() * 1.0 / 0x7fff * 2 - 1;
+            a.y = MSRAND() * 1.0 / 0x7fff * 2 - 1;
+            a.z = MSRAND() * 1.0 / 0x7fff * 2 - 1;
+        } while (vlen(a) < 1);
+        a = vnorm(a);
+        G[3 * i] = a.x; G[3 * i + 1] = a.y; G[3 * i + 2] = a.z;
+    }
+    for (int i = 0; i < n; i++) P[i] = i;
+    for (int i = n - 1; i >= 1; i--) {                     /* suffle, algorithms.h:48-54 */
+        int slct = (int)(MSRAND() * 1.0 / 0x7fff * (i + 1));
+        if (slct > i) slct = i;                            /* rand() == RAND_MAX indexes one past the end in the reference */
+        int32_t tmp = P[slct]; P[slct] = P[i]; P[i] = tmp;
+    }
+#undef MSRAND
+}
+
+/* The colours and the normal a material presents at a hit: plain materials return their fields;
+ * PerlinNoiseNormalMaterial scales them by the noise at the position (material.h:104-108); the
+ * _Blood variant mixes in a vein colour and tilts the normal along the noise gradient
+ * (material.h:128-157, material.cpp:67-87).  setPosition runs in Node::calHit before the normal
+ * is taken (Surface.h:272-283). */
+typedef struct { v3 ambient, diffuse, specular, normal; } surf_t;
+static surf_t material_at(const orc_material *m, const perlin_t *t, v3 pos, v3 normal)
+{
+    surf_t o = { v3p(m->ambient), v3p(m->color), v3p(m->specular), normal };
+    if (m->perlin == ORC_PERLIN_NORMAL) {
+        double noise = perlin_normalized(t, pos, m->perlin_scale);
+        o.ambient = vmul(o.ambient, noise); o.diffuse = vmul(o.diffuse, noise); o.specular = vmul(o.specular, noise);
+    } else if (m->perlin == ORC_PERLIN_BLOOD) {
+        double noise = stdmin(perlin_normalized(t, pos, m->perlin_scale) * 1.5, 1.0);
+        double linenoise = perlin_line(t, pos, m->perlin_scale);
+        /* getNormal, material.cpp:73-87 */
+        v3 vec = V(0, 0, 1);
+        if (viszero(vcross(normal, vec))) vec = V(1, 0, 0);
+        v3 b = vnorm(vcross(normal, vec));
+        v3 tg = vnorm(vcross(b, normal));
+        double dpb = linenoise - perlin_line(t, vadd(pos, vmul(tg, 0.001)), m->perlin_scale);
+        double dpt = linenoise - perlin_line(t, vadd(pos, vmul(b, 0.001)), m->perlin_scale);
+        o.normal = vnorm(vadd(vadd(normal, vmul(vmul(b, dpb), 60)), vmul(vmul(tg, dpt), 60)));
+        double hf1 = stdmin(1.0, stdmax(0.0, stdmax(linenoise - 0.6, 0.6 - linenoise) * 2.5 - 0.05));
+        double hf2 = stdmin(1.0, stdmax(0.0, stdmax(noise - 0.4, 0.4 - noise) * 5 - 0.05));
+        double hf = hf1 * hf2;
+        double ln = 1 - linenoise, high = ln * 1.7, nz = noise / 2.5;
+        v3 centre = V(0.45, 0, 0);
+        v3 veins = vmul(centre, high + nz);
+        o.ambient = vmul(vmul(vadd(vmul(v3p(m->ambient), 1 - nz), veins), hf), 0.35);
+        o.diffuse = vmul(vmul(vadd(vmul(v3p(m->color), 1 - nz), veins), hf), 1.0);
+        /* getSpecular (material.h:150-157) is written without parentheses around its last `&`:
+         * `+` binds tighter than `&` and `*` tighter still, so it is (S&n + C&(1-n)) & (hf*0.85) */
+        o.specular = vmul(vadd(vmul(v3p(m->specular), noise), vmul(centre, 1 - noise)), hf * 0.85);
+    }
+    return o;
+}
+void orc_perlin_material(const orc_material *m, const int32_t *P, const double *G, int n,
+                         const double pos[3], const double normal[3], double out[12])
+{
+    perlin_t t = { P, G, n };
+    surf_t o = material_at(m, &t, v3p(pos), v3p(normal));
+    v3st(out, o.ambient); v3st(out + 3, o.diffuse); v3st(out + 6, o.specular); v3st(out + 9, o.normal);
+}
+
 /* ------------------------------------------------------------------ scene */
 struct orc_scene {
     orc_object *objects;     uint64_t nobjects;
@@ -655,6 +759,7 @@ struct orc_scene {
     double **tri_store;
     uint32_t *prim_base;     /* global primitive id of each object's first primitive */
     v3 background;
+    perlin_t perlin;         /* tables of the Perlin materials (owned copies) */
     otree itree[2];          /* the voxel octree of each implicit kind (HeartShape::ptree is one static tree per class) */
     int has_itree[2];
 };
@@ -673,6 +778,7 @@ void orc_scene_destroy(orc_scene *s)
         onode_free(s->itree[k].root);
         free(s->itree[k].blo); free(s->itree[k].bhi);
     }
+    free((void *)s->perlin.P); free((void *)s->perlin.G);
     free(s->trees); free(s->tri_store); free(s->objects); free(s->materials); free(s->lights);
     free(s->prim_base); free(s);
 }
@@ -694,6 +800,18 @@ orc_scene *orc_scene_create(const orc_scene_desc *d)
     s->trees = (otree *)calloc(d->nmeshes ? d->nmeshes : 1, sizeof(otree));
     s->tri_store = (double **)calloc(d->nmeshes ? d->nmeshes : 1, sizeof(double *));
     s->background = v3p(d->background);
+    {
+        int need = 0;
+        for (uint64_t i = 0; i < d->nmaterials; i++) need |= d->materials[i].perlin != ORC_PERLIN_NONE;
+        if (need) {
+            int n = d->perlin_p && d->perlin_g && d->perlin_n > 0 ? d->perlin_n : 256;
+            int32_t *P = (int32_t *)malloc(n * sizeof(int32_t));
+            double *G = (double *)malloc(3 * n * sizeof(double));
+            if (d->perlin_p && d->perlin_g && d->perlin_n > 0) { memcpy(P, d->perlin_p, n * sizeof(int32_t)); memcpy(G, d->perlin_g, 3 * n * sizeof(double)); }
+            else orc_perlin_tables(12325, n, P, G);        /* SEED, algorithms.h:99 */
+            s->perlin.P = P; s->perlin.G = G; s->perlin.n = n;
+        }
+    }
     for (uint64_t mi = 0; mi < d->nmeshes; mi++) {
         otree *t = &s->trees[mi];
         uint64_t n = d->meshes[mi].ntris;
@@ -827,6 +945,10 @@ static int object_calhit(const orc_scene *s, int oi, ray_t r, double t0, double 
         rec->normal = vnorm(vcross(vsub(v1, v0), vsub(v2, v0)));
     } break;
     }
+    /* Node::getNormal hands the raw normal to the material (Surface.cpp:15-23), which has just
+     * been given the hit position (Surface.h:277) */
+    if (s->materials[o->material].perlin == ORC_PERLIN_BLOOD)
+        rec->normal = material_at(&s->materials[o->material], &s->perlin, vadd(vmul(r.d, t), r.e), rec->normal).normal;
     return 1;
 }
 
@@ -1014,9 +1136,11 @@ static v3 ray_color(const pctx *cx, ray_t ray, double t0, double t1, int jumpTim
     if (!(mat->type & ORC_MAT_MONTECARLO)) {
         /* Phong / Whitted branch, scene.cpp:305-375 */
         if (mat->type & ORC_MAT_NORMAL) {                                /* :307-322 */
+            surf_t sf = { v3p(mat->ambient), v3p(mat->color), v3p(mat->specular), rec.normal };
+            if (mat->perlin != ORC_PERLIN_NONE) sf = material_at(mat, &s->perlin, vadd(vmul(ray.d, rec.t), ray.e), rec.normal);
             for (uint64_t li = 0; li < s->nlights; li++) {
                 const orc_light *L = &s->lights[li];
-                v3 amb = v3p(mat->ambient);
+                v3 amb = sf.ambient;
                 if (mat->check == ORC_CHECK_NORMAL) amb = V(fabs(rec.normal.x), fabs(rec.normal.y), fabs(rec.normal.z));           /* material.h:78 */
                 else if (mat->check == ORC_CHECK_POSITION)                                                                        /* material.h:88-89 */
                     amb = vdivv(vsub(rec.localp, v3p(mat->check_box)), vsub(v3p(mat->check_box + 3), v3p(mat->check_box)));
@@ -1032,9 +1156,9 @@ static v3 ray_color(const pctx *cx, ray_t ray, double t0, double t1, int jumpTim
                 if (!group_hit(s, nr, RT_ZERO, vlen(vsub(lightpos, p)) - RT_ZERO, NULL, cx->c)) {
                     double kd = vdot(rec.normal, nr.d);
                     if (!(0.0 < kd)) kd = 0.0;                           /* max(0.0, n.d) */
-                    color = vadd(color, V(mat->color[0] * (L->diffuse[0] * kd), mat->color[1] * (L->diffuse[1] * kd), mat->color[2] * (L->diffuse[2] * kd)));
+                    color = vadd(color, V(sf.diffuse.x * (L->diffuse[0] * kd), sf.diffuse.y * (L->diffuse[1] * kd), sf.diffuse.z * (L->diffuse[2] * kd)));
                     double ks = pow(vdot(vnorm(vsub(nr.d, ray.d)), rec.normal), mat->shine);
-                    color = vadd(color, V(mat->specular[0] * (L->specular[0] * ks), mat->specular[1] * (L->specular[1] * ks), mat->specular[2] * (L->specular[2] * ks)));
+                    color = vadd(color, V(sf.specular.x * (L->specular[0] * ks), sf.specular.y * (L->specular[1] * ks), sf.specular.z * (L->specular[2] * ks)));
                 }
             }
         }

@@ -36,6 +36,8 @@ enum { ORC_OBJ_SPHERE = 1, ORC_OBJ_GROUND = 2, ORC_OBJ_WALL_Z = 3, ORC_OBJ_WALL_
        ORC_OBJ_GENUS2 = 7 }; /* ImplicitSurface<SurfaceOfGenus2Function> (Surface.h:121-147) */
 /* NormalCheckMaterial / PositionCheckMaterial (material.h:70-92): what getAmbient returns */
 enum { ORC_CHECK_NONE = 0, ORC_CHECK_NORMAL = 1, ORC_CHECK_POSITION = 2 };
+/* PerlinNoiseNormalMaterial / PerlinNoiseNormalMaterial_Blood (material.h:95-164) */
+enum { ORC_PERLIN_NONE = 0, ORC_PERLIN_NORMAL = 1, ORC_PERLIN_BLOOD = 2 };
 enum { ORC_LIGHT_SPHERE = 1, ORC_LIGHT_FACE = 2, ORC_LIGHT_POINT = 3 };
 
 #define ORC_MISS 0xFFFFFFFFu
@@ -59,6 +61,9 @@ typedef struct {
     double  ambient[3], specular[3], mirror[3];   /* Phong branch only (material.h:59-62) */
     double  shine;
     double  check_box[6];  /* PositionCheckMaterial's box: lo, hi */
+    int32_t perlin;        /* ORC_PERLIN_* */
+    int32_t reserved;
+    double  perlin_scale;  /* scale_ of the Perlin materials (material.h:99) */
 } orc_material;
 
 typedef struct {
@@ -91,6 +96,10 @@ typedef struct {
     int32_t octree_max_depth;   /* depth guard, absent in the reference */
     int32_t reserved;
     double  implicit_min_size;  /* half edge of the implicit surfaces' voxels; 0 = 3e-3 (octree.h:66, Surface.h:123) */
+    const int32_t *perlin_p;    /* the Perlin generator's permutation P_ (perlin_n entries) ...     */
+    const double  *perlin_g;    /* ... and unit vectors G_ (3 x perlin_n); NULL = orc_perlin_tables(12325, 256) */
+    int32_t perlin_n;
+    int32_t reserved2;
 } orc_scene_desc;
 
 typedef struct {
@@ -133,6 +142,16 @@ int64_t orc_implicit_boxes(const orc_scene *s, int kind, double *boxes, uint64_t
 /* the implicit function and the analytic normal of a kind at a point of its own frame */
 double orc_implicit_func(int kind, const double pos[3]);
 void orc_implicit_normal(int kind, const double pos[3], double out[3]);
+
+/* algorithm::perlinNoise (algorithms.h:56-87) over given tables */
+double orc_perlin_noise(double x, double y, double z, double scale, const int32_t *P, const double *G, int n);
+/* PerlinNoiseGenerator's constructor (algorithms.cpp:4-19) replayed with the generator the reference
+ * was written for (MSVC rand(): s = s*214013 + 2531011, (s >> 16) & 0x7fff, RAND_MAX 0x7fff) */
+void orc_perlin_tables(uint32_t seed, int n, int32_t *P, double *G);
+/* What a Perlin material returns at position pos for a raw normal: out = ambient, diffuse, specular,
+ * adjusted normal (12 doubles) -- material.h:104-108,128-157, material.cpp:67-87 */
+void orc_perlin_material(const orc_material *m, const int32_t *P, const double *G, int n,
+                         const double pos[3], const double normal[3], double out[12]);
 
 /* Camera::init, camera.cpp:37-48 */
 void orc_camera_init(const double from[3], const double at[3], const double vup[3],

@@ -114,6 +114,48 @@ int rt_camera_init(const double from[3], const double at[3], const double vup[3]
     return 0;
 }
 
+int rt_perlin_tables(uint32_t seed, int n, int32_t *P, double *G)
+{
+    if (n <= 0 || !P || !G) return fail("rt_perlin_tables: bad argument");
+    uint32_t st = seed;                                                     // srand(SEED), algorithms.cpp:7
+    auto next = [&]() { st = st * 214013u + 2531011u; return (int)((st >> 16) & 0x7fff); };
+    for (int i = 0; i < n; i++) {
+        // genRandomUnitVec, algorithms.h:37-46: draws until the point lies OUTSIDE the unit ball, then normalises
+        double a[3], l;
+        do {
+            for (int k = 0; k < 3; k++) a[k] = next() * 1.0 / 0x7fff * 2 - 1;
+            l = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        } while (l < 1);
+        const double inv = 1 / l;
+        for (int k = 0; k < 3; k++) G[3 * i + k] = a[k] * inv;
+    }
+    for (int i = 0; i < n; i++) P[i] = i;
+    for (int i = n - 1; i >= 1; i--) {                                      // suffle, algorithms.h:48-54
+        int pick = (int)(next() * 1.0 / 0x7fff * (i + 1));
+        if (pick > i) pick = i;                                             // rand() == RAND_MAX would index past the end
+        std::swap(P[pick], P[i]);
+    }
+    return 0;
+}
+
+double rt_perlin_noise(double x, double y, double z, double scale, const int32_t *P, const double *G, int n)
+{
+    if (!P || !G || n <= 0) return 0.0;
+    auto fai = [&](int t) { const int m = t % n; return P[m >= 0 ? m : n + m]; };
+    auto weight = [](double t) { const double at = std::fabs(t); return at < 1 ? 2 * at * at * at - 3 * at * at + 1 : 0.0; };
+    x /= scale; y /= scale; z /= scale;
+    double result = 0;
+    for (int c = 0; c < 8; c++) {
+        const int i = (c & 1) ? (int)std::floor(x) : (int)(std::floor(x) + 1);
+        const int j = (c & 2) ? (int)std::floor(y) : (int)(std::floor(y) + 1);
+        const int k = (c & 4) ? (int)std::floor(z) : (int)(std::floor(z) + 1);
+        const double u = x - i, v = y - j, w = z - k;
+        const double *g = G + 3 * fai(i + fai(j + fai(k)));
+        result += weight(u) * weight(v) * weight(w) * (g[0] * u + g[1] * v + g[2] * w);
+    }
+    return result;
+}
+
 int rt_camera_change_fov(const rt_camera *origin, double time, rt_camera *out)
 {
     if (!origin || !out || origin == out) return fail("rt_camera_change_fov: bad argument");
@@ -220,6 +262,30 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     for (uint64_t i = 0; i < d->nmaterials; i++) {
         const rt_material &m = d->materials[i];
         if ((m.type & RT_MAT_TRANSPARENT) && !(m.nr > 0)) return fail("rt_scene_create: transparent material needs nr > 0");
+    }
+    bool need_perlin = false;
+    for (uint64_t i = 0; i < d->nmaterials; i++) {
+        const rt_material &m = d->materials[i];
+        if (m.perlin < RT_PERLIN_NONE || m.perlin > RT_PERLIN_BLOOD) return fail("rt_scene_create: unknown Perlin material kind");
+        if (m.perlin != RT_PERLIN_NONE) {
+            if (!(m.perlin_scale != 0.0) || !std::isfinite(m.perlin_scale)) return fail("rt_scene_create: Perlin material needs a finite, non-zero scale");
+            need_perlin = true;
+        }
+        if (m.check < RT_CHECK_NONE || m.check > RT_CHECK_POSITION) return fail("rt_scene_create: unknown check material kind");
+    }
+    std::vector<int32_t> perlin_p;
+    std::vector<double> perlin_g;
+    if (need_perlin) {
+        const bool given = d->perlin_p && d->perlin_g && d->perlin_n > 0;
+        const int n = given ? d->perlin_n : 256;
+        perlin_p.resize(n); perlin_g.resize(3 * (size_t)n);
+        if (given) {
+            std::memcpy(perlin_p.data(), d->perlin_p, n * sizeof(int32_t));
+            std::memcpy(perlin_g.data(), d->perlin_g, 3 * (size_t)n * sizeof(double));
+            for (int i = 0; i < n; i++) if (perlin_p[i] < 0 || perlin_p[i] >= n) return fail("rt_scene_create: perlin_p entry out of range");
+        } else {
+            rt_perlin_tables(12325, n, perlin_p.data(), perlin_g.data());
+        }
     }
     for (uint64_t i = 0; i < d->nlights; i++) {
         int t = d->lights[i].type;
@@ -330,12 +396,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     for (size_t i = 0; i < leaf_tris.size(); i++)
         leaf_sph[i] = (leaf_tris[i].id & LEAF_VOXEL) ? make_voxel_sphere(leaf_tris[i]) : make_leaf_sphere(leaf_tris[i]);
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
+    void *p_pp = nullptr, *p_pg = nullptr;
     auto up = [&](auto &vec, void **dst) {
         if (e != hipSuccess) return;
         e = upload(vec, dst);
         if (*dst) s->allocs.push_back(*dst);
     };
     up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tris, &p_tris); up(leaf_sph, &p_sph);
+    up(perlin_p, &p_pp); up(perlin_g, &p_pg);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
     if (e != hipSuccess) { rt_scene_destroy(s); return fail_hip("scene upload", e); }
@@ -346,6 +414,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.leaf_tris = (const LeafTri *)p_idx;
     s->dev.leaf_sph = (const LeafSphere *)p_sph;
     s->dev.tris = (const double *)p_tris;
+    s->dev.perlin_p = (const int32_t *)p_pp;
+    s->dev.perlin_g = (const double *)p_pg;
+    s->dev.perlin_n = (int32_t)perlin_p.size();
     s->dev.nobjects = (int32_t)d->nobjects;
     s->dev.nlights = (int32_t)d->nlights;
     s->dev.regular = 1;

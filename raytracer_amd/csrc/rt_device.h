@@ -39,10 +39,14 @@ struct DevScene {
     const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
     const LeafSphere  *leaf_sph;   // one bounding sphere per leaf_tris record (same index)
     const double      *tris;       // v0, e1, e2 (9 doubles) by global triangle index, for shading normals
+    const int32_t     *perlin_p;   // Perlin permutation and unit vectors (perlin_n, 3 x perlin_n); null without Perlin materials
+    const double      *perlin_g;
     int32_t nobjects;
     int32_t nlights;
     int32_t regular;               // every node coordinate is 0 or of magnitude 1e-100 .. 1e100
     int32_t nbig;                  // octrees with inner nodes whose root boxes are listed below (at most RT_MAX_BIG)
+    int32_t perlin_n;
+    int32_t pad;
     double  background[3];
     float   big_lo[4][3], big_hi[4][3];
 };

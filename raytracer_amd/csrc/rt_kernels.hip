@@ -778,6 +778,70 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 
 // Drawable::doAfterHit -> getRawNormal (Surface.cpp:228-231, 68-71; Surface.h:184,197,211);
 // a mesh hit takes the hit triangle's geometric normal.
+// ------------------------------------------------------------------ Perlin materials
+// algorithm::perlinNoise, algorithms.h:56-87
+// (a real call, not inlined: the Perlin materials are rare, and their code must not weigh on the
+// register budget of the kernels that shade every other material)
+__device__ __noinline__ double perlin_noise_call(const int32_t *perlin_p, const double *perlin_g, int n, double px, double py, double pz, double scale)
+{
+    const double x = px / scale, y = py / scale, z = pz / scale;
+    const double fx = floor(x), fy = floor(y), fz = floor(z);
+    double result = 0;
+#pragma unroll 1
+    for (int c = 0; c < 8; c++) {
+        const int i = (c & 1) ? (int)fx : (int)(fx + 1);
+        const int j = (c & 2) ? (int)fy : (int)(fy + 1);
+        const int k = (c & 4) ? (int)fz : (int)(fz + 1);
+        const double u = x - i, v = y - j, w = z - k;
+        int m = k % n;               m = perlin_p[m >= 0 ? m : n + m];
+        m = (j + m) % n;             m = perlin_p[m >= 0 ? m : n + m];
+        m = (i + m) % n;             m = perlin_p[m >= 0 ? m : n + m];
+        const double *g = perlin_g + 3 * m;
+        const double au = fabs(u), av = fabs(v), aw = fabs(w);
+        const double wu = au < 1 ? 2 * au * au * au - 3 * au * au + 1 : 0.0;
+        const double wv = av < 1 ? 2 * av * av * av - 3 * av * av + 1 : 0.0;
+        const double ww = aw < 1 ? 2 * aw * aw * aw - 3 * aw * aw + 1 : 0.0;
+        result += wu * wv * ww * (g[0] * u + g[1] * v + g[2] * w);
+    }
+    return result;
+}
+__device__ inline double perlin_noise(const DevScene &S, V3 p, double scale) { return perlin_noise_call(S.perlin_p, S.perlin_g, S.perlin_n, p.x, p.y, p.z, scale); }
+__device__ inline double perlin_normalized(const DevScene &S, V3 p, double scale) { return perlin_noise(S, p, scale) / 2 + 0.5; }      // algorithms.cpp:37-40
+__device__ inline double perlin_line(const DevScene &S, V3 p, double scale) { return smin(fabs(perlin_noise(S, p, scale)) * 11, 1.0); }  // algorithms.cpp:32-35
+// PerlinNoiseNormalMaterial_Blood::getNormal (material.cpp:73-87) at the position the material
+// was given by Node::calHit (Surface.h:277)
+__device__ inline V3 blood_normal(const DevScene &S, const rt_material &m, V3 pos, V3 normal)
+{
+    const double linenoise = perlin_line(S, pos, m.perlin_scale);
+    V3 vec = mk(0, 0, 1);
+    if (iszero(cross(normal, vec))) vec = mk(1, 0, 0);
+    const V3 b = norm(cross(normal, vec));
+    const V3 t = norm(cross(b, normal));
+    const double dpb = linenoise - perlin_line(S, pos + t * 0.001, m.perlin_scale);
+    const double dpt = linenoise - perlin_line(S, pos + b * 0.001, m.perlin_scale);
+    return norm((normal + (b * dpb) * 60) + (t * dpt) * 60);
+}
+// getAmbient / getDiffuse / getSpecular of the Perlin materials (material.h:104-108, 128-157)
+__device__ inline void perlin_colours(const DevScene &S, const rt_material &m, V3 pos, V3 &amb, V3 &dif, V3 &spe)
+{
+    if (m.perlin == RT_PERLIN_NORMAL) {
+        const double noise = perlin_normalized(S, pos, m.perlin_scale);
+        amb = amb * noise; dif = dif * noise; spe = spe * noise;
+    } else {
+        const double noise = smin(perlin_normalized(S, pos, m.perlin_scale) * 1.5, 1.0);     // material.cpp:67-71
+        const double linenoise = perlin_line(S, pos, m.perlin_scale);
+        const double hf1 = smin(1.0, smax(0.0, smax(linenoise - 0.6, 0.6 - linenoise) * 2.5 - 0.05));
+        const double hf2 = smin(1.0, smax(0.0, smax(noise - 0.4, 0.4 - noise) * 5 - 0.05));
+        const double hf = hf1 * hf2;
+        const double high = (1 - linenoise) * 1.7, nz = noise / 2.5;
+        const V3 centre = mk(0.45, 0, 0), veins = centre * (high + nz);
+        amb = ((amb * (1 - nz) + veins) * hf) * 0.35;
+        dif = ((dif * (1 - nz) + veins) * hf) * 1.0;
+        // getSpecular is written without parentheses around its last `&`: (S&n + C&(1-n)) & (hf*0.85)
+        spe = (spe * noise + centre * (1 - noise)) * (hf * 0.85);
+    }
+}
+
 // HeartShape::getRawNormal (Surface.cpp:239-265) and SurfaceOfGenus2Function::getNormal
 // (Surface.cpp:333-343) at a point of the surface's own frame (y and z swapped as there)
 __device__ inline V3 implicit_normal(int type, V3 pos)
@@ -798,7 +862,7 @@ __device__ inline V3 implicit_normal(int type, V3 pos)
     }
     return norm(n);
 }
-__device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
+__device__ inline V3 raw_normal(const DevScene &S, const Hit &h, V3 p)
 {
     const DevObject &o = S.objects[h.obj];
     if (o.type == RT_OBJ_SPHERE) return norm(p - mk(o.p[0], o.p[1], o.p[2]));
@@ -808,6 +872,13 @@ __device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
     if (o.type == RT_OBJ_WALL_X) return mk(1, 0, 0);
     const double *tr = S.tris + 9ull * h.prim;
     return norm(cross(ld3(tr + 3), ld3(tr + 6)));
+}
+// Node::getNormal, Surface.cpp:15-23: the material may adjust the raw normal
+__device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
+{
+    const V3 n = raw_normal(S, h, p);
+    const rt_material &m = S.materials[S.objects[h.obj].material];
+    return m.perlin == RT_PERLIN_BLOOD ? blood_normal(S, m, p, n) : n;
 }
 __device__ __forceinline__ uint32_t global_prim(const DevScene &S, const Hit &h)
 {
@@ -885,12 +956,26 @@ struct RaySrc {             // rt_trace_rays: caller's ray array
         prim_id[i] = hit ? global_prim(S, h) : RT_MISS;
         if (tout) tout[i] = hit ? h.t : RT_INFINITE;
         if (normal) {
-            V3 nn = mk(0, 0, 0);
-            if (hit) nn = hit_normal(S, h, ld3(rays[i].e) + ld3(rays[i].d) * h.t);
-            normal[3ull * i] = nn.x; normal[3ull * i + 1] = nn.y; normal[3ull * i + 2] = nn.z;
+            // the hit is parked in the ray's normal slot; k_ray_normals turns it into the normal
+            normal[3ull * i] = __longlong_as_double(hit ? (long long)(((uint64_t)(uint32_t)h.obj << 32) | h.prim) : -1ll);
+            normal[3ull * i + 1] = h.t;
         }
     }
 };
+// The normals of rt_trace_rays' hits (Drawable::doAfterHit, Surface.cpp:228-231), from the hits
+// that k_trace_rays left in the normal array.
+__global__ __launch_bounds__(RT_BLOCK) void k_ray_normals(DevScene S, const rt_ray *rays, uint32_t n, double *normal)
+{
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t id = (uint64_t)__double_as_longlong(normal[3ull * i]);
+    V3 nn = mk(0, 0, 0);
+    if (id != ~0ull) {
+        Hit h; h.t = normal[3ull * i + 1]; h.obj = (int32_t)(id >> 32); h.prim = (uint32_t)id;
+        nn = hit_normal(S, h, ld3(rays[i].e) + ld3(rays[i].d) * h.t);
+    }
+    normal[3ull * i] = nn.x; normal[3ull * i + 1] = nn.y; normal[3ull * i + 2] = nn.z;
+}
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(RaySrc src, uint32_t *next, uint64_t *counters)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
@@ -1221,6 +1306,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     }
     // next-event estimation, scene.cpp:223-246; the shadow ray of light 0 is appended together
     // with the lobe rays below, further lights append theirs one by one
+    // the colours the Phong terms use: the material's own, or what a Perlin material makes of them here
+    V3 pamb = ld3(mat.ambient), pdif = mcolor, pspe = ld3(mat.specular);
+    if (phongN && mat.perlin != RT_PERLIN_NONE) perlin_colours(S, mat, p, pamb, pdif, pspe);
     bool want0 = false;
     V3 ldir0 = mk(0, 0, 0), contrib0 = mk(0, 0, 0);
     double dist0 = 0;
@@ -1248,7 +1336,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             }
         } else if (phongN) {                                                 // scene.cpp:307-322
             const rt_light &L = S.lights[li];
-            V3 amb = ld3(mat.ambient);
+            V3 amb = pamb;
             if (mat.check == RT_CHECK_NORMAL) amb = mk(fabs(normal.x), fabs(normal.y), fabs(normal.z));              // material.h:78
             else if (mat.check == RT_CHECK_POSITION) {                                                                // material.h:88-89
                 // HitRecord::localp: the hit in a HeartShape's own frame (Surface.cpp:268-275), zero for any other drawable
@@ -1277,7 +1365,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
             double kd = dot(normal, ldir);
             if (!(0.0 < kd)) kd = 0.0;                                       // max(0.0, n.d)
             const double ks = pow(dot(norm(ldir - rd), normal), mat.shine);
-            contrib = had(W, had(mcolor, ld3(L.diffuse) * kd) + had(ld3(mat.specular), ld3(L.specular) * ks));
+            contrib = had(W, had(pdif, ld3(L.diffuse) * kd) + had(pspe, ld3(L.specular) * ks));
             want = true;                                                     // the shadow test is made whatever it will deliver
         }
         if (li == 0) { want0 = want; ldir0 = ldir; contrib0 = contrib; dist0 = dist; continue; }
@@ -1413,6 +1501,7 @@ hipError_t launch_trace_rays(const DevScene &S, int num_cu, uint32_t *next, cons
     hipError_t e = hipMemsetAsync(next, 0, 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_rays, dim3(engine_blocks(n, num_cu, (const void *)k_trace_rays)), dim3(RT_BLOCK), 0, st, src, next, counters);
+    if (normal) hipLaunchKernelGGL(k_ray_normals, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, S, rays, (uint32_t)n, normal);
     return hipGetLastError();
 }
 hipError_t launch_trace_primary(const DevScene &S, int num_cu, uint32_t *next, const rt_camera &cam, int w, int h, uint32_t *prim_id,

@@ -20,6 +20,8 @@ MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MAT_MONTECARLO = 1, 2, 4, 8
 OBJ_SPHERE, OBJ_GROUND, OBJ_WALL_Z, OBJ_WALL_X, OBJ_MESH, OBJ_HEART, OBJ_GENUS2 = 1, 2, 3, 4, 5, 6, 7
 # NormalCheckMaterial / PositionCheckMaterial (material.h:70-92)
 CHECK_NONE, CHECK_NORMAL, CHECK_POSITION = 0, 1, 2
+# PerlinNoiseNormalMaterial / PerlinNoiseNormalMaterial_Blood (material.h:95-164)
+PERLIN_NONE, PERLIN_NORMAL, PERLIN_BLOOD = 0, 1, 2
 LIGHT_SPHERE, LIGHT_FACE, LIGHT_POINT = 1, 2, 3
 MISS = 0xFFFFFFFF
 
@@ -32,15 +34,15 @@ OBJECT_DT = np.dtype([("type", "<i4"), ("material", "<i4"), ("mesh", "<i4"), ("r
 MATERIAL_DT = np.dtype([("type", "<i4"), ("check", "<i4"), ("emission", "<f8", (3,)),
                         ("color", "<f8", (3,)), ("blur", "<f8"), ("atten", "<f8", (3,)),
                         ("nr", "<f8"), ("ambient", "<f8", (3,)), ("specular", "<f8", (3,)),
-                        ("mirror", "<f8", (3,)), ("shine", "<f8"), ("check_box", "<f8", (6,))],
-                       align=True)
+                        ("mirror", "<f8", (3,)), ("shine", "<f8"), ("check_box", "<f8", (6,)),
+                        ("perlin", "<i4"), ("reserved", "<i4"), ("perlin_scale", "<f8")], align=True)
 LIGHT_DT = np.dtype([("type", "<i4"), ("reserved", "<i4"), ("pos", "<f8", (3,)), ("radius", "<f8"),
                      ("normal", "<f8", (3,)), ("up", "<f8", (3,)), ("right", "<f8", (3,)),
                      ("width", "<f8"), ("height", "<f8"), ("diffuse", "<f8", (3,)),
                      ("ambient", "<f8", (3,)), ("specular", "<f8", (3,))], align=True)
 RAY_DT = np.dtype([("e", "<f8", (3,)), ("d", "<f8", (3,))], align=True)
 
-assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 224 and LIGHT_DT.itemsize == 200
+assert OBJECT_DT.itemsize == 48 and MATERIAL_DT.itemsize == 240 and LIGHT_DT.itemsize == 200
 
 
 class MeshC(C.Structure):
@@ -56,7 +58,8 @@ class SceneDescC(C.Structure):
                 ("tri_box_pad", C.c_double),
                 ("octree_max_size", C.c_int32), ("octree_overlap_tol", C.c_int32),
                 ("octree_max_depth", C.c_int32), ("reserved", C.c_int32),
-                ("implicit_min_size", C.c_double)]
+                ("implicit_min_size", C.c_double),
+                ("perlin_p", C.c_void_p), ("perlin_g", C.c_void_p), ("perlin_n", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class CameraC(C.Structure):
@@ -77,7 +80,7 @@ class SceneDesc:
 
     def __init__(self, objects, materials, lights, meshes, background=(0.0, 0.0, 0.0),
                  tri_box_pad=1e-7, octree_max_size=128, octree_overlap_tol=3, octree_max_depth=12,
-                 implicit_min_size=0.0):
+                 implicit_min_size=0.0, perlin_tables=None):
         self.objects = np.ascontiguousarray(objects, dtype=OBJECT_DT)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DT)
         self.lights = np.ascontiguousarray(lights, dtype=LIGHT_DT)
@@ -88,6 +91,13 @@ class SceneDesc:
         self.octree_overlap_tol = int(octree_overlap_tol)
         self.octree_max_depth = int(octree_max_depth)
         self.implicit_min_size = float(implicit_min_size)   # 0 = the reference's 3e-3
+        # (P, G) of the Perlin generator, or None for the library's replay of the reference's own
+        self.perlin_tables = None
+        if perlin_tables is not None:
+            P = np.ascontiguousarray(perlin_tables[0], np.int32)
+            G = np.ascontiguousarray(perlin_tables[1], np.float64).reshape(-1, 3)
+            assert len(P) == len(G)
+            self.perlin_tables = (P, G)
 
     def to_c(self):
         """Return (SceneDescC, keepalive) -- keepalive must outlive the call that reads it."""
@@ -106,6 +116,9 @@ class SceneDesc:
         d.octree_overlap_tol = self.octree_overlap_tol
         d.octree_max_depth = self.octree_max_depth
         d.implicit_min_size = self.implicit_min_size
+        if self.perlin_tables is not None:
+            d.perlin_p, d.perlin_g = self.perlin_tables[0].ctypes.data, self.perlin_tables[1].ctypes.data
+            d.perlin_n = len(self.perlin_tables[0])
         return d, (mesh_arr, self)
 
     @property

@@ -22,7 +22,7 @@ EXPORTS = (
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
-    "rt_scene_implicit_stats", "rt_scene_implicit_boxes",
+    "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
 )
 
 _lib = None
@@ -66,6 +66,9 @@ def lib():
     L.rt_camera_change_fov.argtypes = [C.POINTER(CameraC), _dbl, C.POINTER(CameraC)]
     L.rt_light_move_face.argtypes = [_vp, _dbl, _vp]
     L.rt_scene_set_light.argtypes = [_vp, _u64, _vp, _vp]
+    L.rt_perlin_tables.argtypes = [C.c_uint32, _int, _vp, _vp]
+    L.rt_perlin_noise.restype = _dbl
+    L.rt_perlin_noise.argtypes = [_dbl, _dbl, _dbl, _dbl, _vp, _vp, _int]
     L.rt_scene_implicit_stats.argtypes = [_vp, _int, C.POINTER(C.c_uint64)]
     L.rt_scene_implicit_boxes.restype = C.c_int64
     L.rt_scene_implicit_boxes.argtypes = [_vp, _int, _vp, _u64]
@@ -123,6 +126,18 @@ def light_move_face(origin, time):
     out = np.zeros(1, LIGHT_DT)
     _chk(lib().rt_light_move_face(src.ctypes.data_as(C.c_void_p), C.c_double(time), out.ctypes.data_as(C.c_void_p)), "rt_light_move_face")
     return out[0]
+
+
+def perlin_tables(seed=12325, n=256):
+    """PerlinNoiseGenerator's tables (algorithms.cpp:4-19; the reference's SEED and size by default)."""
+    P = np.zeros(n, np.int32); G = np.zeros((n, 3), np.float64)
+    _chk(lib().rt_perlin_tables(seed, n, _p(P), _p(G)), "rt_perlin_tables")
+    return P, G
+
+
+def perlin_noise(x, y, z, scale, P, G):
+    P = np.ascontiguousarray(P, np.int32); G = np.ascontiguousarray(G, np.float64)
+    return lib().rt_perlin_noise(x, y, z, scale, _p(P), _p(G), len(P))
 
 
 def save_bmp(bgr, filename):

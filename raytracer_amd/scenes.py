@@ -455,3 +455,32 @@ def heart_example_scene(width=320, height=240, min_size=1e-2):
                      background=(0.06, 0.07, 0.1), implicit_min_size=min_size)
     cam = dict(look_from=(0.6, 3.0, 8.5), look_at=(0.1, 1.3, 0), vup=(0, 1, 0), vfov=40.0, aspect=width * 1.0 / height)
     return desc, cam
+
+
+def perlin_material(kind, ambient, diffuse, specular, shine, scale=1.0):
+    """PerlinNoiseNormalMaterial / PerlinNoiseNormalMaterial_Blood (amb, dif, spe, shi, scale) --
+    material.h:95-164."""
+    m = phong_material(ambient, diffuse, specular, shine)
+    m["perlin"], m["perlin_scale"] = kind, scale
+    return m
+
+
+def perlin_scene(tables=None):
+    """Perlin materials (material.h:95-164) on a sphere, a small mesh, a heart and the ground, under
+    a point Light and a FaceLight: PerlinNoiseNormalMaterial and the _Blood variant (noise-tilted
+    normals, so the mirror of the Phong + mirror sphere next to them sees perturbed surfaces)."""
+    from .desc import PERLIN_BLOOD, PERLIN_NORMAL
+    mats = [perlin_material(PERLIN_NORMAL, (.10, .08, .05), (.80, .70, .40), (.5, .5, .5), 24.0, 0.35),
+            perlin_material(PERLIN_BLOOD, (.30, .25, .25), (.80, .60, .55), (.6, .6, .6), 30.0, 0.5),
+            phong_material((.02, .02, .02), (.10, .10, .12), (.6, .6, .6), 60.0, mirror=(.75, .75, .8)),
+            perlin_material(PERLIN_NORMAL, (.06, .06, .08), (.55, .55, .70), (.1, .1, .1), 4.0, 1.3),
+            perlin_material(PERLIN_BLOOD, (.25, .2, .2), (.7, .5, .5), (.4, .4, .4), 12.0, 0.8)]
+    objs = [sphere((0, 1, 0), 1.0, 0), sphere((2.3, 1, 0.4), 1.0, 2), implicit_object(OBJ_HEART, (-2.4, 1.5, 0.6), 0.9, 1),
+            mesh_object(0, 4), plane(OBJ_GROUND, 0.0, 3), plane(OBJ_WALL_Z, -4.0, 3)]
+    lights = [point_light((4, 7, 5), (.5, .5, .5), (.9, .9, .8), (1, 1, 1)),
+              face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, (.5, .5, .6), ambient=(.2, .2, .2), specular=(.5, .5, .5))]
+    body = blob((0.3, 2.9, 0.2), 0.7, 14, 15, seed=5)
+    desc = SceneDesc(_stack(objs, OBJECT_DT), _stack(mats, MATERIAL_DT), _stack(lights, LIGHT_DT), [body],
+                     background=(0.05, 0.07, 0.1), implicit_min_size=1.5e-2, perlin_tables=tables)
+    cam = dict(look_from=(0.5, 2.8, 9), look_at=(0, 1.2, 0), vup=(0, 1, 0), vfov=42.0, aspect=4 / 3)
+    return desc, cam

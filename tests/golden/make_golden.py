@@ -164,6 +164,21 @@ def main():
         out.update({k + "center": np.array(center), k + "scale": scale, k + "obj_e": rays["e"], k + "obj_d": rays["d"],
                     k + "obj_hit": h, k + "obj_t": t, k + "obj_normal": nrm, k + "obj_localp": lp})
     np.savez_compressed(os.path.join(HERE, "implicit.npz"), **out)
+    # 9. Perlin noise and the Perlin materials (algorithms.h:56-87, material.h:95-164, material.cpp:67-87)
+    #    over the tables the reference's generator builds in this container
+    P, G = orc.ref_perlin_tables(256)
+    rr = np.random.default_rng(909)
+    xyz = np.concatenate([rr.uniform(-300, 300, (300, 3)), rr.uniform(-3, 3, (300, 3))])
+    sc = rr.choice([1.0, 0.37, 2.5], len(xyz))
+    noise = np.array([orc.ref_perlin_noise(x, y, z, s_, P, G) for (x, y, z), s_ in zip(xyz, sc)])
+    amb, dif, spe = (.2, .1, .1), (.7, .5, .4), (.5, .6, .7)
+    pos = rr.uniform(-4, 4, (400, 3))
+    nrm = rr.normal(size=(400, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[::10] = (0.0, 0.0, 1.0)
+    mats = np.stack([np.stack([orc.ref_perlin_material(kind, amb, dif, spe, 20.0, 0.6, P, G, pos[i], nrm[i]) for i in range(len(pos))])
+                     for kind in (1, 2)])
+    np.savez_compressed(os.path.join(HERE, "perlin.npz"), P=P, G=G, xyz=xyz, scale=sc, noise=noise, amb=np.array(amb), dif=np.array(dif),
+                        spe=np.array(spe), shine=20.0, mscale=0.6, pos=pos, normal=nrm, mats=mats)
     print("golden vectors written to", HERE)
 
 

@@ -165,3 +165,17 @@ def test_animated_camera_and_light_are_host_arithmetic_and_match_oracle():
         r = np.sqrt(18.0)
         assert a["pos"][0] == np.sin(t * 2 * 3.1415926) * r and a["pos"][2] == np.cos(t * 2 * 3.1415926) * r
         assert a["pos"][1] == 6.0 and np.array_equal(a["normal"], l0["normal"]) and a["width"] == 2.5
+
+
+def test_perlin_host_functions_match_oracle_and_golden():
+    """rt_perlin_tables / rt_perlin_noise are host arithmetic: same tables as the oracle's replay
+    of the generator, same noise as the values captured from the reference."""
+    P1, G1 = hip.perlin_tables()
+    P2, G2 = orc.perlin_tables()
+    assert np.array_equal(P1, P2) and np.array_equal(G1, G2) and sorted(P1) == list(range(256))
+    P3, G3 = hip.perlin_tables(seed=7, n=64)
+    P4, G4 = orc.perlin_tables(seed=7, n=64)
+    assert np.array_equal(P3, P4) and np.array_equal(G3, G4)
+    with np.load(os.path.join(ROOT, "tests", "golden", "perlin.npz")) as g:
+        for (x, y, z), sc, ref in zip(g["xyz"], g["scale"], g["noise"]):
+            assert hip.perlin_noise(x, y, z, float(sc), g["P"], g["G"]) == ref

@@ -166,3 +166,17 @@ def test_implicit_surfaces_bit_exact(golden_dir, kind):
     prim, t, nrm, _ = s.trace_rays(rays, 0.0, 1e10)
     assert np.array_equal(prim != MISS, g[k + "obj_hit"] != 0) and np.array_equal(t, g[k + "obj_t"])
     assert np.array_equal(nrm, g[k + "obj_normal"]) and (g[k + "obj_hit"] != 0).sum() > 200
+
+
+def test_perlin_bit_exact(golden_dir):
+    g = _load(golden_dir, "perlin")
+    P, G = g["P"], g["G"]
+    for (x, y, z), sc, ref in zip(g["xyz"], g["scale"], g["noise"]):
+        assert orc.perlin_noise(x, y, z, float(sc), P, G) == ref
+    for ki, kind in enumerate((1, 2)):
+        m = scenes.perlin_material(kind, g["amb"], g["dif"], g["spe"], float(g["shine"]), float(g["mscale"]))
+        for i in range(len(g["pos"])):
+            assert np.array_equal(orc.perlin_material(m, P, G, g["pos"][i], g["normal"][i]), g["mats"][ki, i])
+    # the generator replayed with the arithmetic of MSVC's rand(): a permutation and unit vectors
+    P, G = orc.perlin_tables()
+    assert sorted(P) == list(range(256)) and np.allclose(np.linalg.norm(G, axis=1), 1.0, atol=1e-15)

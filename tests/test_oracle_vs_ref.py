@@ -172,3 +172,27 @@ def test_implicit_drawables_match_reference(kind):
     h2, t2, n2, lp2 = orc.ref_implicit_object_hit(kind, center, scale, rays, 0.0, 1e10)
     assert np.array_equal(p1 != MISS, h2 != 0) and np.array_equal(t1, t2) and np.array_equal(n1, n2)
     assert (h2 != 0).sum() > 300
+
+
+def test_perlin_noise_and_materials_match_reference():
+    """algorithm::perlinNoise over the generator's tables, PerlinNoiseNormalMaterial and the
+    _Blood variant (colours and tilted normal) -- algorithms.h:56-87, material.h:95-164,
+    material.cpp:67-87."""
+    P, G = orc.ref_perlin_tables(256)
+    assert sorted(P) == list(range(256)) and np.allclose(np.linalg.norm(G, axis=1), 1.0)
+    rng = np.random.default_rng(77)
+    for _ in range(400):
+        x, y, z = rng.uniform(-300, 300, 3) if rng.random() < 0.5 else rng.uniform(-3, 3, 3)
+        sc = float(rng.choice([1.0, 0.37, 2.5]))
+        assert orc.perlin_noise(x, y, z, sc, P, G) == orc.ref_perlin_noise(x, y, z, sc, P, G)
+    amb, dif, spe = (.2, .1, .1), (.7, .5, .4), (.5, .6, .7)
+    for kind in (1, 2):
+        m = scenes.perlin_material(kind, amb, dif, spe, 20.0, 0.6)
+        for _ in range(300):
+            pos = rng.uniform(-4, 4, 3)
+            nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+            if rng.random() < 0.1:
+                nrm = np.array([0.0, 0.0, 1.0])
+            a = orc.perlin_material(m, P, G, pos, nrm)
+            b = orc.ref_perlin_material(kind, amb, dif, spe, 20.0, 0.6, P, G, pos, nrm)
+            assert np.array_equal(a, b), (kind, pos, a, b)
