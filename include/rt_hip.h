@@ -243,6 +243,12 @@ int rt_scene_get_profile(rt_scene *scene, double out[6], int reset);
 int rt_resolve_bgr8(const double *radiance_sum, int width, int height, int spp, uint8_t *bgr,
                     void *stream);
 int rt_resolve_bgr8_host(const double *radiance_sum, int width, int height, int spp, uint8_t *bgr);
+/* The same with a tone reproduction operator applied to the averaged colour before the clamp:
+ * SigmoidMethod / SqrtMethod::reproduction (tonereproductionmethod.h:11-35; the reference only
+ * names them in a commented-out line, scene.cpp:109). */
+enum { RT_TONE_NONE = 0, RT_TONE_SIGMOID = 1, RT_TONE_SQRT = 2 };
+int rt_resolve_tone_bgr8(const double *radiance_sum, int width, int height, int spp, int tone, uint8_t *bgr, void *stream);
+int rt_resolve_tone_bgr8_host(const double *radiance_sum, int width, int height, int spp, int tone, uint8_t *bgr);
 
 /* Snapshot (bmpgenerator.cpp:3-45) with fixed-width header fields: 14 + 40 byte headers,
  * 24 bpp, bottom-up rows, no row padding (as the reference writes it). */

@@ -338,6 +338,8 @@ public:
     void setSeed(uint64_t s) { seed_ = s; }
     void setFaceForward(bool on) { faceForward_ = on; }
     void setOctree(int maxSize, int maxDepth) { octMax_ = maxSize; octDepth_ = maxDepth; dirty_ = true; }
+    // tonereproductionmethod.h:11-35 (RT_TONE_SIGMOID / RT_TONE_SQRT), applied by saveToBpm and queryColor
+    void setToneReproduction(int tone) { tone_ = tone; }
     void setImplicitMinSize(double s) { implicitMin_ = s; dirty_ = true; }      // octree.h:66 (3e-3 when 0)
     // RTObject::setTime cascade (RTObject.h:110-117, main.cpp:85): the camera and the lights follow
     // the clock; a moved light is patched into the uploaded scene, nothing is rebuilt.
@@ -370,7 +372,11 @@ public:
         if (!run_ || x >= (unsigned)px_ || y >= (unsigned)py_) return -1;
         const double inv = 1.0 / (n_ * m_);
         const double *s = &sum_[((size_t)y * px_ + x) * 3];
-        auto reg = [](double v) { return v > 1.0 ? 1.0 : (v < 0 ? 0.0 : v); };
+        auto reg = [&](double v) {
+            if (tone_ == RT_TONE_SIGMOID) v = 1.0 / (1 + std::exp(-(2 * v - 1))) * 2.164 - 0.582;
+            else if (tone_ == RT_TONE_SQRT) v = v > 1 ? std::pow(v, 1.0 / 2) : v;
+            return v > 1.0 ? 1.0 : (v < 0 ? 0.0 : v);
+        };
         color = Color(reg(s[0] * inv), reg(s[1] * inv), reg(s[2] * inv), 0);
         return 0;
     }
@@ -378,7 +384,7 @@ public:
     {
         if (!run_) return -1;
         std::vector<uint8_t> bgr((size_t)px_ * py_ * 3);
-        if (rt_resolve_bgr8_host(sum_.data(), px_, py_, n_ * m_, bgr.data())) return -1;
+        if (rt_resolve_tone_bgr8_host(sum_.data(), px_, py_, n_ * m_, tone_, bgr.data())) return -1;
         return rt_save_bmp(bgr.data(), px_, py_, filename) ? -1 : 0;
     }
     const char *lastError() const { return rt_last_error(); }
@@ -418,6 +424,7 @@ private:
     int n_ = 20, m_ = 20, maxJump_ = 40, rusJump_ = 12;                      // scene.h:52-54
     int octMax_ = 128, octDepth_ = 12;                                       // octree.h:50
     double implicitMin_ = 0;
+    int tone_ = RT_TONE_NONE;
     uint64_t seed_ = 1243;                                                   // scene.cpp:22
     rt_scene *handle_ = nullptr;
     std::vector<double> sum_;

@@ -65,6 +65,9 @@ def lib():
         L.orc_render_range.argtypes = [C.c_void_p, C.POINTER(CameraC), C.POINTER(RenderParamsC),
                                        C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_resolve_bgr8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_resolve_tone_bgr8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_tone.restype = C.c_double
+        L.orc_tone.argtypes = [C.c_int, C.c_double]
         L.orc_hit_box.argtypes = [_dp, _dp, C.c_void_p, C.c_double, C.c_double, _dp, _dp]
         L.orc_sphere_hit.argtypes = [_dp, C.c_double, C.c_void_p, C.c_double, C.c_double, _dp]
         L.orc_plane_hit.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_double, _dp]
@@ -218,12 +221,16 @@ def camera_get_ray(cam, s, t):
     return r[0]
 
 
-def resolve_bgr8(radiance_sum, spp):
+def resolve_bgr8(radiance_sum, spp, tone=0):
     h, w, _ = radiance_sum.shape
     a = np.ascontiguousarray(radiance_sum, np.float64)
     out = np.empty((h, w, 3), np.uint8)
-    lib().orc_resolve_bgr8(_p(a), w, h, spp, _p(out))
+    lib().orc_resolve_tone_bgr8(_p(a), w, h, spp, tone, _p(out))
     return out
+
+
+def tone(kind, x):
+    return lib().orc_tone(kind, float(x))
 
 
 def _ray1(e, d):
@@ -330,6 +337,7 @@ def ref():
         R.ref_perlin_noise.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         R.ref_perlin_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         R.ref_perlin_material.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _dp]
+        R.ref_tone.argtypes = [C.c_int, _dp, _dp]
         for f in ("ref_const_zero", "ref_const_infinite", "ref_const_pi"):
             getattr(R, f).restype = C.c_double
         _ref = R
@@ -496,3 +504,9 @@ def ref_perlin_material(kind, amb, dif, spe, shine, scale, P, G, pos, normal):
     out = (C.c_double * 12)()
     ref().ref_perlin_material(kind, _d3(amb), _d3(dif), _d3(spe), shine, scale, _p(P), _p(G), len(P), _d3(pos), _d3(normal), out)
     return np.array(out[:]).reshape(4, 3)
+
+
+def ref_tone(kind, rgb):
+    out = (C.c_double * 3)()
+    ref().ref_tone(kind, _d3(rgb), out)
+    return np.array(out[:])

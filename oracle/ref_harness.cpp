@@ -40,6 +40,7 @@
 #include "material.h"
 #include "light.h"
 #include "camera.h"
+#include "tonereproductionmethod.h"
 #undef private
 #undef protected
 
@@ -414,6 +415,14 @@ void ref_perlin_material(int kind, const double amb[3], const double dif[3], con
     out[3] = cd.x_; out[4] = cd.y_; out[5] = cd.z_;
     out[6] = cs.x_; out[7] = cs.y_; out[8] = cs.z_;
     st(out + 9, nn);
+}
+
+// SigmoidMethod (1) / SqrtMethod (2)::reproduction, tonereproductionmethod.h:11-35
+void ref_tone(int method, const double in[3], double out[3])
+{
+    Color c(in[0], in[1], in[2], 1);
+    Color r = method == 1 ? SigmoidMethod().reproduction(c) : SqrtMethod().reproduction(c);
+    out[0] = r.x_; out[1] = r.y_; out[2] = r.z_;
 }
 
 // RTObject::calRandom structure check (RTObject.cpp:46-69) cannot be run on glibc

@@ -1393,13 +1393,21 @@ int orc_render(const orc_scene *s, const orc_camera *cam, const orc_render_param
     return orc_render_range(s, cam, p, 0, (uint64_t)p->width * (uint64_t)p->height, radiance_sum, counters, threads);
 }
 
-void orc_resolve_bgr8(const double *sum, int w, int h, int spp, uint8_t *bgr)
+/* SigmoidMethod / SqrtMethod::reproduction, tonereproductionmethod.h:11-35, per channel */
+double orc_tone(int tone, double x)
+{
+    if (tone == ORC_TONE_SIGMOID) return 1.0 / (1 + exp(-(2 * x - 1))) * 2.164 - 0.582;
+    if (tone == ORC_TONE_SQRT) return x > 1 ? pow(x, 1.0 / 2) : x;
+    return x;
+}
+void orc_resolve_bgr8(const double *sum, int w, int h, int spp, uint8_t *bgr) { orc_resolve_tone_bgr8(sum, w, h, spp, ORC_TONE_NONE, bgr); }
+void orc_resolve_tone_bgr8(const double *sum, int w, int h, int spp, int tone, uint8_t *bgr)
 {
     double inv = 1.0 / spp;                       /* scene.cpp:112: color * (1.0 / (n * n)) */
     for (uint64_t i = 0; i < (uint64_t)w * (uint64_t)h; i++) {
         double c[3];
         for (int k = 0; k < 3; k++) {
-            double v = sum[3 * i + k] * inv;
+            double v = orc_tone(tone, sum[3 * i + k] * inv);
             if (v > 1.0) v = 1.0; else if (v < 0) v = 0;   /* regularize, types.h:167-177 */
             c[k] = v;
         }

@@ -186,6 +186,11 @@ int orc_render_range(const orc_scene *s, const orc_camera *c, const orc_render_p
                      uint64_t counters[4], int threads);
 /* average, regularize (types.h:167-177), int(c*255) as B,G,R bytes (scene.cpp:183-185) */
 void orc_resolve_bgr8(const double *radiance_sum, int w, int h, int spp, uint8_t *bgr);
+/* the same with a tone reproduction operator (tonereproductionmethod.h:11-35) applied to the
+ * averaged colour before it is clamped */
+enum { ORC_TONE_NONE = 0, ORC_TONE_SIGMOID = 1, ORC_TONE_SQRT = 2 };
+double orc_tone(int tone, double x);
+void orc_resolve_tone_bgr8(const double *sum, int w, int h, int spp, int tone, uint8_t *bgr);
 
 /* unit-level entry points for known-answer tests */
 int    orc_hit_box(const double lo[3], const double hi[3], const orc_ray *r, double t0, double t1,

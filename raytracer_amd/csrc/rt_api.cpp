@@ -714,9 +714,15 @@ int rt_scene_get_profile(rt_scene *s, double out[6], int reset)
 
 int rt_resolve_bgr8(const double *radiance_sum, int w, int h, int spp, uint8_t *bgr, void *stream)
 {
+    return rt_resolve_tone_bgr8(radiance_sum, w, h, spp, RT_TONE_NONE, bgr, stream);
+}
+
+int rt_resolve_tone_bgr8(const double *radiance_sum, int w, int h, int spp, int tone, uint8_t *bgr, void *stream)
+{
     if (!radiance_sum || !bgr) return fail("rt_resolve_bgr8: null buffer");
     if (w <= 0 || h <= 0 || spp <= 0) return fail("rt_resolve_bgr8: bad size");
-    HIP_TRY(launch_resolve(radiance_sum, (uint64_t)w * h, spp, bgr, (hipStream_t)stream));
+    if (tone < RT_TONE_NONE || tone > RT_TONE_SQRT) return fail("rt_resolve_bgr8: unknown tone operator");
+    HIP_TRY(launch_resolve(radiance_sum, (uint64_t)w * h, spp, tone, bgr, (hipStream_t)stream));
     return 0;
 }
 
@@ -803,13 +809,18 @@ int rt_render_host(rt_scene *s, const rt_camera *cam, const rt_render_params *p,
 
 int rt_resolve_bgr8_host(const double *radiance_sum, int w, int h, int spp, uint8_t *bgr)
 {
+    return rt_resolve_tone_bgr8_host(radiance_sum, w, h, spp, RT_TONE_NONE, bgr);
+}
+
+int rt_resolve_tone_bgr8_host(const double *radiance_sum, int w, int h, int spp, int tone, uint8_t *bgr)
+{
     if (!radiance_sum || !bgr) return fail("rt_resolve_bgr8_host: null buffer");
     if (w <= 0 || h <= 0 || spp <= 0) return fail("rt_resolve_bgr8_host: bad size");
     const size_t n = (size_t)w * h;
     DevBuf ds, db;
     HIP_TRY(ds.alloc(n * 24)); HIP_TRY(db.alloc(n * 3));
     HIP_TRY(hipMemcpy(ds.p, radiance_sum, n * 24, hipMemcpyHostToDevice));
-    if (int rc = rt_resolve_bgr8((const double *)ds.p, w, h, spp, (uint8_t *)db.p, nullptr)) return rc;
+    if (int rc = rt_resolve_tone_bgr8((const double *)ds.p, w, h, spp, tone, (uint8_t *)db.p, nullptr)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(bgr, db.p, n * 3, hipMemcpyDeviceToHost));
     return 0;

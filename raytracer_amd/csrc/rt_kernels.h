@@ -19,6 +19,6 @@ hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const Wav
                         int ray_class, hipStream_t st);
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
                         const RayDest &dst, hipStream_t st);
-hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st);
+hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, int tone, uint8_t *bgr, hipStream_t st);
 
 } // namespace rt

@@ -1460,7 +1460,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
 }
 
 // colorArray_ -> bytes: average, regularize (types.h:167-177), int(c*255) as B,G,R (scene.cpp:183-185)
-__global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, uint8_t *bgr)
+// with tone != 0 a tone reproduction operator acts on the average first: SigmoidMethod (1) /
+// SqrtMethod (2)::reproduction, tonereproductionmethod.h:11-35
+__global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, int tone, uint8_t *bgr)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -1468,6 +1470,8 @@ __global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, uin
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         double v = sum[3 * i + k] * inv;
+        if (tone == RT_TONE_SIGMOID) v = 1.0 / (1 + exp(-(2 * v - 1))) * 2.164 - 0.582;
+        else if (tone == RT_TONE_SQRT) v = v > 1 ? pow(v, 1.0 / 2) : v;
         if (v > 1.0) v = 1.0; else if (v < 0) v = 0;
         c[k] = v;
     }
@@ -1536,11 +1540,11 @@ hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &sr
     hipLaunchKernelGGL(k_shade, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, src, base, count, dst);
     return hipGetLastError();
 }
-hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, uint8_t *bgr, hipStream_t st)
+hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, int tone, uint8_t *bgr, hipStream_t st)
 {
     if (npix == 0) return hipSuccess;
     double inv = 1.0 / spp;                                   // scene.cpp:112
-    hipLaunchKernelGGL(k_resolve_bgr8, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, sum, npix, inv, bgr);
+    hipLaunchKernelGGL(k_resolve_bgr8, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, sum, npix, inv, tone, bgr);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ EXPORTS = (
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
+    "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host",
 )
 
 _lib = None
@@ -66,6 +67,8 @@ def lib():
     L.rt_camera_change_fov.argtypes = [C.POINTER(CameraC), _dbl, C.POINTER(CameraC)]
     L.rt_light_move_face.argtypes = [_vp, _dbl, _vp]
     L.rt_scene_set_light.argtypes = [_vp, _u64, _vp, _vp]
+    L.rt_resolve_tone_bgr8.argtypes = [_vp, _int, _int, _int, _int, _vp, _vp]
+    L.rt_resolve_tone_bgr8_host.argtypes = [_vp, _int, _int, _int, _int, _vp]
     L.rt_perlin_tables.argtypes = [C.c_uint32, _int, _vp, _vp]
     L.rt_perlin_noise.restype = _dbl
     L.rt_perlin_noise.argtypes = [_dbl, _dbl, _dbl, _dbl, _vp, _vp, _int]
@@ -146,11 +149,14 @@ def save_bmp(bgr, filename):
     _chk(lib().rt_save_bmp(_p(bgr), w, h, os.fsencode(filename)), "rt_save_bmp")
 
 
-def resolve_bgr8_host(radiance_sum, spp):
+TONE_NONE, TONE_SIGMOID, TONE_SQRT = 0, 1, 2
+
+
+def resolve_bgr8_host(radiance_sum, spp, tone=TONE_NONE):
     a = np.ascontiguousarray(radiance_sum, np.float64)
     h, w, _ = a.shape
     out = np.empty((h, w, 3), np.uint8)
-    _chk(lib().rt_resolve_bgr8_host(_p(a), w, h, int(spp), _p(out)), "rt_resolve_bgr8_host")
+    _chk(lib().rt_resolve_tone_bgr8_host(_p(a), w, h, int(spp), int(tone), _p(out)), "rt_resolve_tone_bgr8_host")
     return out
 
 

@@ -179,6 +179,10 @@ def main():
                      for kind in (1, 2)])
     np.savez_compressed(os.path.join(HERE, "perlin.npz"), P=P, G=G, xyz=xyz, scale=sc, noise=noise, amb=np.array(amb), dif=np.array(dif),
                         spe=np.array(spe), shine=20.0, mscale=0.6, pos=pos, normal=nrm, mats=mats)
+    # 10. tone reproduction operators (tonereproductionmethod.h:11-35)
+    x = rr.uniform(-0.5, 6.0, (400, 3))
+    np.savez_compressed(os.path.join(HERE, "tone.npz"), x=x, sigmoid=np.stack([orc.ref_tone(1, v) for v in x]),
+                        sqrt=np.stack([orc.ref_tone(2, v) for v in x]))
     print("golden vectors written to", HERE)
 
 

@@ -591,3 +591,16 @@ def test_perlin_materials(golden_dir, tables):
     i2, k2 = sg.render(c, prm)
     assert np.array_equal(k1, k2) and np.sqrt((((i1 - i2) / 4) ** 2).mean()) <= RMSE_TOL
     assert i1.std() > 0.1
+
+
+def test_resolve_with_tone_operators():
+    """rt_resolve_tone_bgr8: SigmoidMethod / SqrtMethod on the averaged colour, then clamp and
+    int(c*255) -- bytes equal to the oracle's except where the device's exp / pow differ from
+    glibc's in the last bit right at a byte boundary."""
+    rng = np.random.default_rng(8)
+    img = rng.uniform(-0.2, 5.0, (64, 96, 3)) * 16
+    for tone in (hip.TONE_NONE, hip.TONE_SIGMOID, hip.TONE_SQRT):
+        a = hip.resolve_bgr8_host(img, 16, tone)
+        b = orc.resolve_bgr8(img, 16, tone)
+        assert (a != b).mean() < 1e-3 and np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert not np.array_equal(hip.resolve_bgr8_host(img, 16, hip.TONE_SIGMOID), hip.resolve_bgr8_host(img, 16))

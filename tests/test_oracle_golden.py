@@ -180,3 +180,9 @@ def test_perlin_bit_exact(golden_dir):
     # the generator replayed with the arithmetic of MSVC's rand(): a permutation and unit vectors
     P, G = orc.perlin_tables()
     assert sorted(P) == list(range(256)) and np.allclose(np.linalg.norm(G, axis=1), 1.0, atol=1e-15)
+
+
+def test_tone_operators_bit_exact(golden_dir):
+    g = _load(golden_dir, "tone")
+    for x, a, b in zip(g["x"], g["sigmoid"], g["sqrt"]):
+        assert np.array_equal([orc.tone(1, v) for v in x], a) and np.array_equal([orc.tone(2, v) for v in x], b)

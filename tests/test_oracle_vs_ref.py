@@ -196,3 +196,12 @@ def test_perlin_noise_and_materials_match_reference():
             a = orc.perlin_material(m, P, G, pos, nrm)
             b = orc.ref_perlin_material(kind, amb, dif, spe, 20.0, 0.6, P, G, pos, nrm)
             assert np.array_equal(a, b), (kind, pos, a, b)
+
+
+def test_tone_operators_match_reference():
+    """SigmoidMethod / SqrtMethod::reproduction, tonereproductionmethod.h:11-35."""
+    rng = np.random.default_rng(5)
+    for kind in (1, 2):
+        for _ in range(300):
+            rgb = rng.uniform(-0.5, 6.0, 3)
+            assert np.array_equal([orc.tone(kind, v) for v in rgb], orc.ref_tone(kind, rgb))
