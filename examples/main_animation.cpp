@@ -2,12 +2,14 @@
 // per step, scene->setTime(time) before each render) written against include/rt_scene.hpp with
 // the reference's animated classes: a ChangeFovCamera (camera.cpp:74-94) and a MovableFaceLight
 // (light.cpp:87-107) over Phong / mirror / glass spheres.  Frames are written as BMP files
-// <prefix>NNN.bmp (the reference packs them into an AVI through OpenCV, AviSaver.cpp).
+// <prefix>NNN.bmp and, as in the reference, into <prefix>anim.avi through AviSaver (uncompressed
+// here; the reference's goes through OpenCV's MJPG encoder).
 //   usage: main_animation [width height n frames prefix]   (defaults 160 120 2 8 frame_)
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "rt_scene.hpp"
 using namespace rt_host;
@@ -43,6 +45,9 @@ int main(int argc, char **argv)
     scene->addLight(std::make_shared<MovableFaceLight>(Vec3(-3, 6, 3), Vec3(0.4, -1, -0.3), Vec3(0, 0, 1), 2.5, 1.5,
                                                        Color(.2, .2, .2, 0), Color(.5, .5, .6, 0), Color(.5, .5, .5, 0)));
 
+    AviSaver avi;                                                            // main.cpp:76-81
+    avi.Open(prefix + "anim.avi", px, py, 15, 1);
+    std::vector<uint8_t> allData((size_t)px * py * 3);
     double time = 0;
     for (int count = 0; count < frames; time += 0.015, count++) {           // main.cpp:83
         if (scene->setTime(time)) { std::fprintf(stderr, "setTime failed: %s\n", scene->lastError()); return 1; }
@@ -50,7 +55,17 @@ int main(int argc, char **argv)
         char name[512];
         std::snprintf(name, sizeof name, "%s%03d.bmp", prefix.c_str(), count);
         if (scene->saveToBpm(name)) { std::fprintf(stderr, "saveToBpm failed: %s\n", scene->lastError()); return 1; }
+        for (int i = 0; i < py; i++)                                         // main.cpp:89-98
+            for (int j = 0; j < px; j++) {
+                Color color;
+                scene->queryColor(j, i, color);
+                allData[((size_t)i * px + j) * 3 + 2] = (uint8_t)int(color.x_ * 255);
+                allData[((size_t)i * px + j) * 3 + 1] = (uint8_t)int(color.y_ * 255);
+                allData[((size_t)i * px + j) * 3 + 0] = (uint8_t)int(color.z_ * 255);
+            }
+        avi.AddImg(allData.data());
         std::printf("time %.3f -> %s (%llu rays)\n", time, name, (unsigned long long)scene->raysTraced());
     }
+    avi.Save();
     return 0;
 }

@@ -431,4 +431,40 @@ private:
     uint64_t rays_[4] = {0, 0, 0, 0};
 };
 
+// AviSaver.h:6-24.  Frames go into an uncompressed AVI (the reference hands them to OpenCV's
+// MJPG encoder); with loop > 1 the frames are kept and written `loop` times by Save().
+class AviSaver {
+public:
+    AviSaver() = default;
+    ~AviSaver() { if (avi_) rt_avi_close(avi_); }
+    AviSaver(const AviSaver &) = delete;
+    AviSaver &operator=(const AviSaver &) = delete;
+    void Open(const std::string &path, int width, int height, double fps, unsigned int loop = 1)
+    {
+        if (avi_) { rt_avi_close(avi_); avi_ = nullptr; }
+        rt_avi_open(path.c_str(), width, height, fps, &avi_);
+        width_ = width; height_ = height; loop_ = (int)loop;
+    }
+    bool isOpen() const { return avi_ != nullptr; }
+    // pdata: height rows of width B,G,R bytes, bottom row first (what main.cpp:87-99 fills in)
+    void AddImg(const uint8_t *pdata)
+    {
+        if (!avi_) return;
+        if (loop_ == 1) rt_avi_add_frame(avi_, pdata);
+        else kept_.emplace_back(pdata, pdata + (size_t)width_ * height_ * 3);
+    }
+    void AddImg(const std::vector<uint8_t> &rgbs) { if (rgbs.size() >= (size_t)width_ * height_ * 3) AddImg(rgbs.data()); }
+    void Save()                                                              // AviSaver.cpp:44-53; also finishes the file
+    {
+        if (!avi_) return;
+        if (loop_ > 1) for (int i = 0; i < loop_; i++) for (const auto &f : kept_) rt_avi_add_frame(avi_, f.data());
+        rt_avi_close(avi_);
+        avi_ = nullptr;
+    }
+private:
+    rt_avi *avi_ = nullptr;
+    int width_ = 0, height_ = 0, loop_ = 1;
+    std::vector<std::vector<uint8_t>> kept_;
+};
+
 } // namespace rt_host

@@ -853,4 +853,93 @@ int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename)
     return ok ? 0 : fail("rt_save_bmp: short write");
 }
 
+// ---------------------------------------------------------------- AVI container (host only)
+} // extern "C"
+struct rt_avi {
+    FILE *f = nullptr;
+    int w = 0, h = 0;
+    uint32_t stride = 0, frames = 0;
+    double fps = 15;
+    long movi_start = 0;
+};
+namespace {
+void le32(FILE *f, uint32_t v) { unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)}; std::fwrite(b, 1, 4, f); }
+void le16(FILE *f, uint16_t v) { unsigned char b[2] = {(unsigned char)v, (unsigned char)(v >> 8)}; std::fwrite(b, 1, 2, f); }
+void tag(FILE *f, const char *t) { std::fwrite(t, 1, 4, f); }
+// header with the frame count and sizes known so far; rewritten by rt_avi_close
+void avi_header(rt_avi *a)
+{
+    FILE *f = a->f;
+    const uint32_t frame_bytes = a->stride * (uint32_t)a->h, n = a->frames;
+    const uint32_t movi_size = 4 + n * (8 + frame_bytes), idx_size = n * 16;
+    std::fseek(f, 0, SEEK_SET);
+    tag(f, "RIFF"); le32(f, 4 + (8 + 4 + (8 + 56) + (8 + 4 + (8 + 56) + (8 + 40))) + (8 + movi_size) + (8 + idx_size)); tag(f, "AVI ");
+    tag(f, "LIST"); le32(f, 4 + (8 + 56) + (8 + 4 + (8 + 56) + (8 + 40))); tag(f, "hdrl");
+    tag(f, "avih"); le32(f, 56);
+    le32(f, (uint32_t)(1e6 / a->fps + 0.5));            // microseconds per frame
+    le32(f, (uint32_t)(frame_bytes * a->fps + 0.5));     // max bytes per second
+    le32(f, 0); le32(f, 0x10);                           // padding granularity, flags: AVIF_HASINDEX
+    le32(f, n); le32(f, 0); le32(f, 1); le32(f, frame_bytes);
+    le32(f, (uint32_t)a->w); le32(f, (uint32_t)a->h);
+    le32(f, 0); le32(f, 0); le32(f, 0); le32(f, 0);
+    tag(f, "LIST"); le32(f, 4 + (8 + 56) + (8 + 40)); tag(f, "strl");
+    tag(f, "strh"); le32(f, 56);
+    tag(f, "vids"); tag(f, "DIB "); le32(f, 0); le16(f, 0); le16(f, 0); le32(f, 0);
+    le32(f, 1000); le32(f, (uint32_t)(a->fps * 1000 + 0.5));   // scale, rate: rate / scale = frames per second
+    le32(f, 0); le32(f, n); le32(f, frame_bytes); le32(f, 0xFFFFFFFFu); le32(f, 0);
+    le16(f, 0); le16(f, 0); le16(f, (uint16_t)a->w); le16(f, (uint16_t)a->h);
+    tag(f, "strf"); le32(f, 40);
+    le32(f, 40); le32(f, (uint32_t)a->w); le32(f, (uint32_t)a->h); le16(f, 1); le16(f, 24); le32(f, 0);   // BI_RGB, positive height: bottom-up
+    le32(f, frame_bytes); le32(f, 0); le32(f, 0); le32(f, 0); le32(f, 0);
+    tag(f, "LIST"); le32(f, movi_size); tag(f, "movi");
+    a->movi_start = std::ftell(f);
+}
+}
+extern "C" {
+
+int rt_avi_open(const char *path, int width, int height, double fps, rt_avi **out)
+{
+    if (!path || !out) return fail("rt_avi_open: null argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || !(fps > 0)) return fail("rt_avi_open: bad size or frame rate");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(std::string("rt_avi_open: cannot open ") + path);
+    rt_avi *a = new rt_avi;
+    a->f = f; a->w = width; a->h = height; a->fps = fps;
+    a->stride = ((uint32_t)width * 3u + 3u) & ~3u;
+    avi_header(a);
+    *out = a;
+    return 0;
+}
+
+int rt_avi_add_frame(rt_avi *a, const uint8_t *bgr)
+{
+    if (!a || !a->f || !bgr) return fail("rt_avi_add_frame: null argument");
+    const uint64_t frame_bytes = (uint64_t)a->stride * a->h;
+    if ((a->frames + 1ull) * (frame_bytes + 24) > 0xF0000000ull) return fail("rt_avi_add_frame: file would exceed the 4 GB RIFF limit");
+    tag(a->f, "00db"); le32(a->f, (uint32_t)frame_bytes);
+    const unsigned char zero[4] = {0, 0, 0, 0};
+    for (int y = 0; y < a->h; y++) {
+        if (std::fwrite(bgr + (size_t)y * a->w * 3, 1, (size_t)a->w * 3, a->f) != (size_t)a->w * 3) return fail("rt_avi_add_frame: write failed");
+        std::fwrite(zero, 1, a->stride - (uint32_t)a->w * 3u, a->f);
+    }
+    a->frames++;
+    return 0;
+}
+
+int rt_avi_close(rt_avi *a)
+{
+    if (!a) return 0;
+    int rc = 0;
+    if (a->f) {
+        const uint32_t frame_bytes = a->stride * (uint32_t)a->h;
+        tag(a->f, "idx1"); le32(a->f, a->frames * 16);
+        for (uint32_t i = 0; i < a->frames; i++) { tag(a->f, "00db"); le32(a->f, 0x10); le32(a->f, 4 + i * (8 + frame_bytes)); le32(a->f, frame_bytes); }
+        avi_header(a);
+        if (std::fclose(a->f) != 0) rc = fail("rt_avi_close: close failed");
+    }
+    delete a;
+    return rc;
+}
+
 } // extern "C"

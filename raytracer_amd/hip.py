@@ -23,7 +23,7 @@ EXPORTS = (
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
-    "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host",
+    "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_add_frame", "rt_avi_close",
 )
 
 _lib = None
@@ -69,6 +69,9 @@ def lib():
     L.rt_scene_set_light.argtypes = [_vp, _u64, _vp, _vp]
     L.rt_resolve_tone_bgr8.argtypes = [_vp, _int, _int, _int, _int, _vp, _vp]
     L.rt_resolve_tone_bgr8_host.argtypes = [_vp, _int, _int, _int, _int, _vp]
+    L.rt_avi_open.argtypes = [C.c_char_p, _int, _int, _dbl, C.POINTER(_vp)]
+    L.rt_avi_add_frame.argtypes = [_vp, _vp]
+    L.rt_avi_close.argtypes = [_vp]
     L.rt_perlin_tables.argtypes = [C.c_uint32, _int, _vp, _vp]
     L.rt_perlin_noise.restype = _dbl
     L.rt_perlin_noise.argtypes = [_dbl, _dbl, _dbl, _dbl, _vp, _vp, _int]
@@ -141,6 +144,32 @@ def perlin_tables(seed=12325, n=256):
 def perlin_noise(x, y, z, scale, P, G):
     P = np.ascontiguousarray(P, np.int32); G = np.ascontiguousarray(G, np.float64)
     return lib().rt_perlin_noise(x, y, z, scale, _p(P), _p(G), len(P))
+
+
+class AviWriter:
+    """AviSaver (AviSaver.cpp:9-75) without a codec: uncompressed frames in an AVI container.
+    Frames are (h, w, 3) uint8 arrays in the layout of resolve_bgr8 (row 0 = bottom, B,G,R)."""
+
+    def __init__(self, path, width, height, fps=15.0):
+        self._h = _vp()
+        self.shape = (height, width, 3)
+        _chk(lib().rt_avi_open(os.fsencode(path), width, height, float(fps), C.byref(self._h)), "rt_avi_open")
+
+    def add(self, bgr):
+        a = np.ascontiguousarray(bgr, np.uint8)
+        assert a.shape == self.shape
+        _chk(lib().rt_avi_add_frame(self._h, _p(a)), "rt_avi_add_frame")
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            _chk(lib().rt_avi_close(h), "rt_avi_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def save_bmp(bgr, filename):

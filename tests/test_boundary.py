@@ -179,3 +179,43 @@ def test_perlin_host_functions_match_oracle_and_golden():
     with np.load(os.path.join(ROOT, "tests", "golden", "perlin.npz")) as g:
         for (x, y, z), sc, ref in zip(g["xyz"], g["scale"], g["noise"]):
             assert hip.perlin_noise(x, y, z, float(sc), g["P"], g["G"]) == ref
+
+
+def test_avi_container_round_trip(tmp_path):
+    """rt_avi_*: RIFF/AVI with uncompressed bottom-up 24-bit frames (the container AviSaver's
+    OpenCV writer produces, AviSaver.cpp:57-64, minus the MJPG codec), parsed back chunk by chunk."""
+    import struct
+    rng = np.random.default_rng(3)
+    W, H, N = 18, 7, 5                                     # 3*W = 54 is not a multiple of 4: rows are padded
+    frames = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    f = str(tmp_path / "a.avi")
+    with hip.AviWriter(f, W, H, 15.0) as avi:
+        for fr in frames:
+            avi.add(fr)
+    raw = open(f, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and struct.unpack_from("<I", raw, 4)[0] == len(raw) - 8
+    pos, chunks = 12, {}
+    while pos < len(raw):
+        tag, size = raw[pos:pos + 4], struct.unpack_from("<I", raw, pos + 4)[0]
+        chunks[(tag, raw[pos + 8:pos + 12] if tag == b"LIST" else b"")] = (pos + 8, size)
+        pos += 8 + size + (size & 1)
+    assert pos == len(raw)
+    (hoff, hsize), (moff, msize), (ioff, isize) = chunks[(b"LIST", b"hdrl")], chunks[(b"LIST", b"movi")], chunks[(b"idx1", b"")]
+    assert raw[hoff + 4:hoff + 8] == b"avih"
+    us, _, _, flags, total, _, streams, _, w, h = struct.unpack_from("<10I", raw, hoff + 12)
+    assert (us, total, streams, w, h) == (66667, N, 1, W, H) and flags & 0x10
+    assert raw[hoff + 76:hoff + 84] == b"strlstrh" and raw[hoff + 88:hoff + 96] == b"vidsDIB "
+    scale, rate = struct.unpack_from("<2I", raw, hoff + 88 + 20)
+    assert rate / scale == 15.0
+    stride = (3 * W + 3) & ~3
+    pos = moff + 4
+    for i in range(N):
+        assert raw[pos:pos + 4] == b"00db" and struct.unpack_from("<I", raw, pos + 4)[0] == stride * H
+        rows = np.frombuffer(raw, np.uint8, stride * H, pos + 8).reshape(H, stride)
+        assert np.array_equal(rows[:, :3 * W].reshape(H, W, 3), frames[i])
+        ck, fl, off, sz = struct.unpack_from("<4sIII", raw, ioff + 16 * i)
+        assert ck == b"00db" and moff + off == pos and sz == stride * H
+        pos += 8 + stride * H
+    assert pos == moff + msize and isize == 16 * N
+    with pytest.raises(hip.RtError):
+        hip.AviWriter(str(tmp_path / "no_such_dir" / "b.avi"), W, H)

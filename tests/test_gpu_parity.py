@@ -474,6 +474,11 @@ def test_cpp_animation_example_matches_oracle(tmp_path):
         assert (got != exp).mean() < 2e-3, f
         assert prev is None or not np.array_equal(prev, got)
         prev = got
+    # the same frames went into the AVI through AviSaver: last frame of the file = last BMP
+    raw = open(tmp_path / "f_anim.avi", "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI "
+    tail = raw.rfind(b"idx1")
+    assert np.array_equal(np.frombuffer(raw[tail - W * H * 3:tail], np.uint8).reshape(H, W, 3), got)
 
 
 def _implicit_desc(kind, center=(0, 0, 0), scale=1.0, min_size=0.0):
