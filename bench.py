@@ -90,11 +90,19 @@ def main():
     rank, local_rank, world = dist_env()
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("for --gpus > 1 launch with torch.distributed.run --nproc-per-node N")
+    # one rank per GPU; RT_BENCH_BACKEND=gloo lets several ranks share a card to rehearse the N > 1
+    # path on a one-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     hip.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W = H = a.size
     n = a.spp_root

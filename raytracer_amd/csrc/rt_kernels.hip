@@ -328,7 +328,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     const FlatNode *nd = S.nodes + T.cur;
     const double lo0 = nd->lo[0], lo1 = nd->lo[1], lo2 = nd->lo[2];
     const double hi0 = nd->hi[0], hi1 = nd->hi[1], hi2 = nd->hi[2];
-    const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count;
+    const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count, nd_voxels = nd->pad;
     // per-axis plane distances; the node's own slab test and all 8 child tests use them
     const double al0 = qdiv<FAST>(lo0 - e.x, d.x, r.x), al1 = qdiv<FAST>(lo1 - e.y, d.y, r.y), al2 = qdiv<FAST>(lo2 - e.z, d.z, r.z);
     const double ah0 = qdiv<FAST>(hi0 - e.x, d.x, r.x), ah1 = qdiv<FAST>(hi1 - e.y, d.y, r.y), ah2 = qdiv<FAST>(hi2 - e.z, d.z, r.z);
@@ -418,7 +418,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         T.k = obj_begin; T.kend = obj_begin + obj_count;
         T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
         T.leaf = child_base == 0;
-        run_bt1[tid] = n1;                                  // only voxel records read it back
+        if (nd_voxels) run_bt1[tid] = n1;                   // voxel records read it back
     }
 }
 

@@ -351,7 +351,7 @@ bool build_implicit_octree(int kind, double min_size, int max_size, int overlap_
     // a voxel travels in a triangle record: v0 = lower corner, e1 = upper corner, e2[0] = length of
     // the diagonal (what BoxNode::calHit moves the entry point back by, Surface.cpp:55), and the
     // top bit of the id says that the record is a voxel
-    return build_flat(pbox, all, max_size, overlap_tol, max_depth, [&](uint32_t o) {
+    const bool ok = build_flat(pbox, all, max_size, overlap_tol, max_depth, [&](uint32_t o) {
         LeafTri lt;
         const Box &b = pbox[o];
         const double dx = b.lo[0] - b.hi[0], dy = b.lo[1] - b.hi[1], dz = b.lo[2] - b.hi[2];
@@ -360,6 +360,8 @@ bool build_implicit_octree(int kind, double min_size, int max_size, int overlap_
         lt.id = o | LEAF_VOXEL; lt.pad = 0;
         return lt;
     }, out, err);
+    for (FlatNode &f : out.nodes) f.pad = 1;          // marks a node whose primitives are voxels
+    return ok;
 }
 
 } // namespace rt

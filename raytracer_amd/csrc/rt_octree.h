@@ -17,7 +17,7 @@ struct FlatNode {
     uint32_t child_base;
     uint32_t obj_begin;   // first record of this node's triangle run
     uint32_t obj_count;
-    uint32_t pad;
+    uint32_t pad;         // 1: the node's primitives are voxels of an implicit surface
 };
 static_assert(sizeof(FlatNode) == 64, "FlatNode must be 64 bytes");
 
