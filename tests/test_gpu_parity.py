@@ -56,6 +56,17 @@ def _mesh_desc(tris, **kw):
                      [tris], **kw)
 
 
+def _example(name):
+    """Path of a built program under examples/ (built here with g++ if the tree came without it)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", name)
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")], timeout=300)
+    assert os.path.exists(exe), f"examples/{name} is not built (__graft_entry__.build())"
+    return exe
+
+
 def test_device_present_and_native_library_loaded():
     assert hip.device_count() >= 1
     assert os.path.exists(hip.LIB_PATH)
@@ -386,8 +397,7 @@ def test_cpp_scene_api_example_matches_oracle(tmp_path):
     """examples/main_kaleidoscope (the reference driver's scene written against
     include/rt_scene.hpp, run as its own process) against the oracle's render of that scene."""
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "main_kaleidoscope")
-    assert os.path.exists(exe), "examples/main_kaleidoscope is not built (__graft_entry__.build())"
+    exe = _example("main_kaleidoscope")
     W, H, n = 102, 63, 3
     out = str(tmp_path / "k.bmp")
     subprocess.check_call([exe, str(W), str(H), str(n), out], timeout=120)
@@ -457,8 +467,7 @@ def test_cpp_animation_example_matches_oracle(tmp_path):
     include/rt_scene.hpp, its own process) against the oracle, frame by frame."""
     import subprocess
     from raytracer_amd.parallel import frame_times
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "main_animation")
-    assert os.path.exists(exe), "examples/main_animation is not built (__graft_entry__.build())"
+    exe = _example("main_animation")
     W, H, n, nframes = 80, 60, 2, 4
     subprocess.check_call([exe, str(W), str(H), str(n), str(nframes), str(tmp_path / "f_")], timeout=120)
     desc, cam, li = scenes.animation_scene(W, H)
@@ -553,8 +562,7 @@ def test_cpp_heart_example_matches_oracle(tmp_path):
     """examples/main_heart (HeartShape, SurfaceOfGenus2, NormalCheckMaterial through
     include/rt_scene.hpp, its own process) against the oracle's render of that scene."""
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "main_heart")
-    assert os.path.exists(exe), "examples/main_heart is not built (__graft_entry__.build())"
+    exe = _example("main_heart")
     W, H, n, ms = 96, 72, 2, 2e-2
     out = str(tmp_path / "h.bmp")
     subprocess.check_call([exe, str(W), str(H), str(n), str(ms), out], timeout=120)
