@@ -617,3 +617,36 @@ def test_resolve_with_tone_operators():
         b = orc.resolve_bgr8(img, 16, tone)
         assert (a != b).mean() < 1e-3 and np.abs(a.astype(int) - b.astype(int)).max() <= 1
     assert not np.array_equal(hip.resolve_bgr8_host(img, 16, hip.TONE_SIGMOID), hip.resolve_bgr8_host(img, 16))
+
+
+def test_benchmark_frame_full_size_properties():
+    """The benchmark frame itself (69 574-triangle mesh in the triangle Cornell box, 1024 x 1024
+    at 256 spp): whole image rows against the oracle at full sample count, additivity over
+    sample slices (what the multi-GPU reduce relies on), run-to-run agreement, and the ray
+    count as the sum of the slices' counts."""
+    desc, cam = scenes.bunny_cornell_scene()
+    sg, so = hip.HipScene(desc), orc.OracleScene(desc)
+    c = hip.camera_init(**cam)
+    W = H = 1024
+    n = 16
+    prm = render_params(W, H, n, seed=1243)
+    whole, k = sg.render(c, prm)
+    assert int(k[0]) > W * H * n * n * 5                     # several rays per path
+    # three whole rows at the full 256 spp against the CPU oracle
+    for y in (97, 512, 901):
+        row, ko = so.render(orc.camera_init(**cam), prm, threads=16, pix_range=(W * y, W * y + W))
+        got, exp = whole[y], row[y]
+        assert np.sqrt((((got - exp) / (n * n)) ** 2).mean()) <= RMSE_TOL
+        assert (_rel(got, exp) > PATH_RTOL).mean() <= 1e-3
+        assert exp.mean() > 1.0
+    # two sample slices (ranks of a 2-GPU job) add up to the whole frame, rays included
+    acc = np.zeros_like(whole)
+    rays = 0
+    for b, e in ((0, 128), (128, 256)):
+        _, kk = sg.render(c, render_params(W, H, n, sample_begin=b, sample_end=e, seed=1243), acc)
+        rays += int(kk[0])
+    assert rays == int(k[0])
+    assert np.abs(acc - whole).max() <= 1e-9 * max(1.0, np.abs(whole).max())
+    # a second run differs by the order of the atomic adds only
+    again, k2 = sg.render(c, prm)
+    assert np.array_equal(k, k2) and np.abs(again - whole).max() <= 1e-9 * max(1.0, np.abs(whole).max())
