@@ -171,6 +171,14 @@ int64_t rt_scene_implicit_boxes(const rt_scene *scene, int kind, double *boxes, 
  * P[n], G[3n].  algorithm::perlinNoise (algorithms.h:56-87) over given tables, host arithmetic. */
 int rt_perlin_tables(uint32_t seed, int n, int32_t *P, double *G);
 double rt_perlin_noise(double x, double y, double z, double scale, const int32_t *P, const double *G, int n);
+/* PerlinNoiseGeneratorWithTime::timeChanged (algorithms.cpp:57-77) under RTObject::setTime
+ * (RTObject.h:110-117): the unit vectors G drift from frame to frame.  `clock` carries the
+ * generator's static count / stage / stime between calls (start from zeros); prev_time is the time
+ * of the previous call, as the generator's own getTime() would report it.  Host arithmetic. */
+typedef struct { int32_t count, stage; double stime; } rt_perlin_clock;
+int rt_perlin_time_changed(rt_perlin_clock *clock, double prev_time, double time, int n, double *G);
+/* Replaces the Perlin tables of an uploaded scene (n must be the size it was created with). */
+int rt_scene_set_perlin(rt_scene *scene, const int32_t *P, const double *G, int n, void *stream);
 
 /* Camera::Camera -> init, camera.cpp:5-8,37-48 (host arithmetic) */
 int rt_camera_init(const double look_from[3], const double look_at[3], const double vup[3],

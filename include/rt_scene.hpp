@@ -345,6 +345,13 @@ public:
     // the clock; a moved light is patched into the uploaded scene, nothing is rebuilt.
     int setTime(double time)
     {
+        // Perlin materials own generators whose vectors drift with time (algorithms.cpp:57-77)
+        if (usesPerlin()) {
+            ensurePerlin();
+            rt_perlin_time_changed(&perlinClock_, time_, time, 256, perlinG_.data());
+            if (handle_ && !dirty_ && rt_scene_set_perlin(handle_, perlinP_.data(), perlinG_.data(), 256, nullptr)) return -1;
+        }
+        time_ = time;
         if (camera_) camera_->setTime(time);
         for (size_t i = 0; i < lights_.size(); i++)
             if (lights_[i]->setTime(time) && handle_ && !dirty_)
@@ -411,6 +418,9 @@ private:
         d.background[0] = background_.x_; d.background[1] = background_.y_; d.background[2] = background_.z_;
         d.tri_box_pad = 1e-7; d.octree_max_size = octMax_; d.octree_overlap_tol = 3; d.octree_max_depth = octDepth_;
         d.implicit_min_size = implicitMin_;
+        bool perlin = false;
+        for (const rt_material &m : mats) perlin = perlin || m.perlin != RT_PERLIN_NONE;
+        if (perlin) { ensurePerlin(); d.perlin_p = perlinP_.data(); d.perlin_g = perlinG_.data(); d.perlin_n = 256; }
         if (rt_scene_create(&d, &handle_)) return -1;
         dirty_ = false;
         return 0;
@@ -423,6 +433,23 @@ private:
     bool run_ = false, dirty_ = true, faceForward_ = false;
     int n_ = 20, m_ = 20, maxJump_ = 40, rusJump_ = 12;                      // scene.h:52-54
     int octMax_ = 128, octDepth_ = 12;                                       // octree.h:50
+    bool usesPerlin() const
+    {
+        std::vector<rt_object> objs; std::vector<rt_material> mats; std::vector<std::vector<double>> meshes;
+        if (!node_ || node_->flatten(objs, mats, meshes)) return false;
+        for (const rt_material &m : mats) if (m.perlin != RT_PERLIN_NONE) return true;
+        return false;
+    }
+    void ensurePerlin()
+    {
+        if (!perlinP_.empty()) return;
+        perlinP_.resize(256); perlinG_.resize(3 * 256);
+        rt_perlin_tables(12325, 256, perlinP_.data(), perlinG_.data());      // SEED, N: algorithms.h:91,99
+    }
+    std::vector<int32_t> perlinP_;
+    std::vector<double> perlinG_;
+    rt_perlin_clock perlinClock_{0, 0, 0.0};
+    double time_ = 0;
     double implicitMin_ = 0;
     int tone_ = RT_TONE_NONE;
     uint64_t seed_ = 1243;                                                   // scene.cpp:22

@@ -49,6 +49,7 @@ def lib():
         L.orc_perlin_noise.restype = C.c_double
         L.orc_perlin_noise.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_perlin_tables.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_perlin_time_changed.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]
         L.orc_perlin_material.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.orc_camera_init.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(CameraC)]
         L.orc_camera_get_ray.argtypes = [C.POINTER(CameraC), C.c_double, C.c_double, C.c_void_p]
@@ -205,6 +206,12 @@ def perlin_tables(seed=12325, n=256):
     return P, G
 
 
+def perlin_time_changed(clock, prev_time, time, G):
+    """clock: a raytracer_amd.hip.PerlinClockC-compatible ctypes struct; G updated in place."""
+    assert G.dtype == np.float64 and G.flags.c_contiguous
+    lib().orc_perlin_time_changed(C.byref(clock), float(prev_time), float(time), len(G), _p(G))
+
+
 def perlin_material(mat, P, G, pos, normal):
     """ambient, diffuse, specular, adjusted normal of a MATERIAL_DT record at `pos`."""
     from raytracer_amd.desc import MATERIAL_DT
@@ -337,6 +344,7 @@ def ref():
         R.ref_perlin_noise.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         R.ref_perlin_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         R.ref_perlin_material.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _dp]
+        R.ref_perlin_time_changed.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_void_p]
         R.ref_tone.argtypes = [C.c_int, _dp, _dp]
         for f in ("ref_const_zero", "ref_const_infinite", "ref_const_pi"):
             getattr(R, f).restype = C.c_double
@@ -510,3 +518,11 @@ def ref_tone(kind, rgb):
     out = (C.c_double * 3)()
     ref().ref_tone(kind, _d3(rgb), out)
     return np.array(out[:])
+
+
+def ref_perlin_time_changed(count, stage, stime, prev_time, time, G):
+    """Returns (count, stage, stime) after the reference's timeChanged; G updated in place."""
+    clk = (C.c_int32 * 2)(count, stage)
+    st = C.c_double(stime)
+    ref().ref_perlin_time_changed(clk, C.byref(st), prev_time, time, len(G), _p(G))
+    return clk[0], clk[1], st.value

@@ -425,6 +425,23 @@ void ref_tone(int method, const double in[3], double out[3])
     out[0] = r.x_; out[1] = r.y_; out[2] = r.z_;
 }
 
+// PerlinNoiseGeneratorWithTime::timeChanged (algorithms.cpp:57-77) on given tables and static state.
+// clock = {count, stage}; G is updated in place.
+void ref_perlin_time_changed(int32_t clock[2], double *stime, double prev_time, double time, int n, double *G)
+{
+    using Gen = algorithm::PerlinNoiseGeneratorWithTime;
+    algorithm::PerlinNoiseGenerator::P_.assign(n, 0);
+    for (int i = 0; i < n; i++) algorithm::PerlinNoiseGenerator::P_[i] = i;
+    algorithm::PerlinNoiseGenerator::G_.clear();
+    for (int i = 0; i < n; i++) algorithm::PerlinNoiseGenerator::G_.push_back(Vec3(G[3 * i], G[3 * i + 1], G[3 * i + 2]));
+    Gen gen(n);
+    Gen::count = clock[0]; Gen::stage = clock[1]; Gen::stime = *stime;
+    gen.time_ = prev_time;
+    gen.timeChanged(time);
+    clock[0] = Gen::count; clock[1] = Gen::stage; *stime = Gen::stime;
+    for (int i = 0; i < n; i++) st(G + 3 * i, algorithm::PerlinNoiseGenerator::G_[i]);
+}
+
 // RTObject::calRandom structure check (RTObject.cpp:46-69) cannot be run on glibc
 // (RAND_MAX + 1 overflows); only the table layout constants are exposed.
 double ref_const_zero(void) { return ZERO; }

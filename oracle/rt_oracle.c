@@ -705,6 +705,19 @@ void orc_perlin_tables(uint32_t seed, int n, int32_t *P, double *G)
 #undef MSRAND
 }
 
+void orc_perlin_time_changed(orc_perlin_clock *clk, double prev_time, double time, int n, double *G)
+{
+    if (time == clk->stime) return;
+    double dt = time - prev_time;
+    if (clk->count % 6 == 0) { clk->count = 1; clk->stage++; }   /* the vectors drawn here are never used */
+    else clk->count++;
+    for (int i = 0; i < n; i++) {
+        v3 g = vadd(v3p(G + 3 * i), vmul(vmul(v3p(G + 3 * ((i + clk->stage) % n)), dt), 5));
+        v3st(G + 3 * i, vnorm(g));
+    }
+    clk->stime = time;
+}
+
 /* The colours and the normal a material presents at a hit: plain materials return their fields;
  * PerlinNoiseNormalMaterial scales them by the noise at the position (material.h:104-108); the
  * _Blood variant mixes in a vein colour and tilts the normal along the noise gradient

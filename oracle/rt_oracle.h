@@ -148,6 +148,9 @@ double orc_perlin_noise(double x, double y, double z, double scale, const int32_
 /* PerlinNoiseGenerator's constructor (algorithms.cpp:4-19) replayed with the generator the reference
  * was written for (MSVC rand(): s = s*214013 + 2531011, (s >> 16) & 0x7fff, RAND_MAX 0x7fff) */
 void orc_perlin_tables(uint32_t seed, int n, int32_t *P, double *G);
+/* PerlinNoiseGeneratorWithTime::timeChanged, algorithms.cpp:57-77; clock = {count, stage} + stime */
+typedef struct { int32_t count, stage; double stime; } orc_perlin_clock;
+void orc_perlin_time_changed(orc_perlin_clock *clock, double prev_time, double time, int n, double *G);
 /* What a Perlin material returns at position pos for a raw normal: out = ambient, diffuse, specular,
  * adjusted normal (12 doubles) -- material.h:104-108,128-157, material.cpp:67-87 */
 void orc_perlin_material(const orc_material *m, const int32_t *P, const double *G, int n,

@@ -156,6 +156,38 @@ double rt_perlin_noise(double x, double y, double z, double scale, const int32_t
     return result;
 }
 
+int rt_perlin_time_changed(rt_perlin_clock *clk, double prev_time, double time, int n, double *G)
+{
+    if (!clk || !G || n <= 0) return fail("rt_perlin_time_changed: bad argument");
+    if (time == clk->stime) return 0;
+    const double dt = time - prev_time;
+    // every sixth change starts a new stage (the random vectors the reference draws at that point
+    // are never read, algorithms.cpp:62-70)
+    if (clk->count % 6 == 0) { clk->count = 1; clk->stage++; }
+    else clk->count++;
+    for (int i = 0; i < n; i++) {                                           // algorithms.cpp:71-74, in place and in order
+        const double *o = G + 3 * ((i + clk->stage) % n);
+        double v[3];
+        for (int k = 0; k < 3; k++) v[k] = G[3 * i + k] + o[k] * dt * 5;
+        const double inv = 1 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int k = 0; k < 3; k++) G[3 * i + k] = v[k] * inv;
+    }
+    clk->stime = time;
+    return 0;
+}
+
+int rt_scene_set_perlin(rt_scene *s, const int32_t *P, const double *G, int n, void *stream)
+{
+    if (!s || !P || !G) return fail("rt_scene_set_perlin: null argument");
+    if (n <= 0 || n != s->dev.perlin_n) return fail("rt_scene_set_perlin: the scene was created with tables of another size (or without Perlin materials)");
+    for (int i = 0; i < n; i++) if (P[i] < 0 || P[i] >= n) return fail("rt_scene_set_perlin: P entry out of range");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync((void *)s->dev.perlin_p, P, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync((void *)s->dev.perlin_g, G, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
 int rt_camera_change_fov(const rt_camera *origin, double time, rt_camera *out)
 {
     if (!origin || !out || origin == out) return fail("rt_camera_change_fov: bad argument");

@@ -24,6 +24,7 @@ EXPORTS = (
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
     "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_add_frame", "rt_avi_close",
+    "rt_perlin_time_changed", "rt_scene_set_perlin",
 )
 
 _lib = None
@@ -72,6 +73,8 @@ def lib():
     L.rt_avi_open.argtypes = [C.c_char_p, _int, _int, _dbl, C.POINTER(_vp)]
     L.rt_avi_add_frame.argtypes = [_vp, _vp]
     L.rt_avi_close.argtypes = [_vp]
+    L.rt_perlin_time_changed.argtypes = [C.POINTER(PerlinClockC), _dbl, _dbl, _int, _vp]
+    L.rt_scene_set_perlin.argtypes = [_vp, _vp, _vp, _int, _vp]
     L.rt_perlin_tables.argtypes = [C.c_uint32, _int, _vp, _vp]
     L.rt_perlin_noise.restype = _dbl
     L.rt_perlin_noise.argtypes = [_dbl, _dbl, _dbl, _dbl, _vp, _vp, _int]
@@ -132,6 +135,17 @@ def light_move_face(origin, time):
     out = np.zeros(1, LIGHT_DT)
     _chk(lib().rt_light_move_face(src.ctypes.data_as(C.c_void_p), C.c_double(time), out.ctypes.data_as(C.c_void_p)), "rt_light_move_face")
     return out[0]
+
+
+class PerlinClockC(C.Structure):
+    """PerlinNoiseGeneratorWithTime's static count / stage / stime (algorithms.cpp:42-45)."""
+    _fields_ = [("count", C.c_int32), ("stage", C.c_int32), ("stime", C.c_double)]
+
+
+def perlin_time_changed(clock, prev_time, time, G):
+    """PerlinNoiseGeneratorWithTime::timeChanged (algorithms.cpp:57-77): G is updated in place."""
+    assert G.dtype == np.float64 and G.flags.c_contiguous
+    _chk(lib().rt_perlin_time_changed(C.byref(clock), float(prev_time), float(time), len(G), _p(G)), "rt_perlin_time_changed")
 
 
 def perlin_tables(seed=12325, n=256):
@@ -277,6 +291,11 @@ class HipScene:
         out = np.empty((n, 6), np.float64)
         lib().rt_scene_implicit_boxes(self._h, kind, _p(out), n)
         return out
+
+    def set_perlin(self, P, G, stream=0):
+        """Replace the Perlin tables of the uploaded scene (animated noise)."""
+        P = np.ascontiguousarray(P, np.int32); G = np.ascontiguousarray(G, np.float64)
+        _chk(lib().rt_scene_set_perlin(self._h, _p(P), _p(G), len(P), stream or None), "rt_scene_set_perlin")
 
     def set_light(self, index, light, stream=0):
         """Replace light `index` (a LIGHT_DT record) of the uploaded scene."""

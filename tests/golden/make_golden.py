@@ -177,7 +177,14 @@ def main():
     nrm[::10] = (0.0, 0.0, 1.0)
     mats = np.stack([np.stack([orc.ref_perlin_material(kind, amb, dif, spe, 20.0, 0.6, P, G, pos[i], nrm[i]) for i in range(len(pos))])
                      for kind in (1, 2)])
-    np.savez_compressed(os.path.join(HERE, "perlin.npz"), P=P, G=G, xyz=xyz, scale=sc, noise=noise, amb=np.array(amb), dif=np.array(dif),
+    # the generator's vectors after 20 frames of the driver's clock (algorithms.cpp:57-77)
+    Gt = G.copy()
+    count = stage = 0
+    stime = prev = tt = 0.0
+    for _ in range(20):
+        count, stage, stime = orc.ref_perlin_time_changed(count, stage, stime, prev, tt, Gt)
+        prev, tt = tt, tt + 0.015
+    np.savez_compressed(os.path.join(HERE, "perlin.npz"), G_after_20=Gt, clock_after_20=np.array([count, stage, stime]), P=P, G=G, xyz=xyz, scale=sc, noise=noise, amb=np.array(amb), dif=np.array(dif),
                         spe=np.array(spe), shine=20.0, mscale=0.6, pos=pos, normal=nrm, mats=mats)
     # 10. tone reproduction operators (tonereproductionmethod.h:11-35)
     x = rr.uniform(-0.5, 6.0, (400, 3))

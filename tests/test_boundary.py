@@ -179,6 +179,16 @@ def test_perlin_host_functions_match_oracle_and_golden():
     with np.load(os.path.join(ROOT, "tests", "golden", "perlin.npz")) as g:
         for (x, y, z), sc, ref in zip(g["xyz"], g["scale"], g["noise"]):
             assert hip.perlin_noise(x, y, z, float(sc), g["P"], g["G"]) == ref
+        # the vectors' drift over 20 frames of the driver's clock (algorithms.cpp:57-77)
+        Ga, Gb = g["G"].copy(), g["G"].copy()
+        ca, cb = hip.PerlinClockC(), hip.PerlinClockC()
+        prev = t = 0.0
+        for _ in range(20):
+            hip.perlin_time_changed(ca, prev, t, Ga)
+            orc.perlin_time_changed(cb, prev, t, Gb)
+            prev, t = t, t + 0.015
+        assert np.array_equal(Ga, g["G_after_20"]) and np.array_equal(Gb, g["G_after_20"])
+        assert [ca.count, ca.stage, ca.stime] == list(g["clock_after_20"])
 
 
 def test_avi_container_round_trip(tmp_path):

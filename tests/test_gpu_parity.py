@@ -650,3 +650,28 @@ def test_benchmark_frame_full_size_properties():
     # a second run differs by the order of the atomic adds only
     again, k2 = sg.render(c, prm)
     assert np.array_equal(k, k2) and np.abs(again - whole).max() <= 1e-9 * max(1.0, np.abs(whole).max())
+
+
+def test_perlin_tables_drift_with_time():
+    """rt_scene_set_perlin: the generator's vectors after some frames of the driver's clock are
+    patched into the uploaded scene; the frame equals the oracle's for a scene built with them."""
+    P, G = hip.perlin_tables()
+    desc, cam = scenes.perlin_scene((P, G.copy()))
+    sg = hip.HipScene(desc)
+    c = hip.camera_init(**cam)
+    W, H, n = 64, 48, 2
+    prm = render_params(W, H, n, seed=7, max_jump=8)
+    first, _ = sg.render(c, prm)
+    clk = hip.PerlinClockC()
+    prev = t = 0.0
+    for _ in range(9):
+        hip.perlin_time_changed(clk, prev, t, G)
+        prev, t = t, t + 0.015
+    sg.set_perlin(P, G)
+    i2, k2 = sg.render(c, prm)
+    desc2, _ = scenes.perlin_scene((P, G))
+    i1, k1 = orc.OracleScene(desc2).render(orc.camera_init(**cam), prm)
+    assert np.array_equal(k1, k2) and np.sqrt((((i1 - i2) / (n * n)) ** 2).mean()) <= RMSE_TOL
+    assert np.abs(first - i2).max() > 1e-3
+    with pytest.raises(hip.RtError):
+        sg.set_perlin(P[:64], G[:64])

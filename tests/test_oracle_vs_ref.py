@@ -205,3 +205,22 @@ def test_tone_operators_match_reference():
         for _ in range(300):
             rgb = rng.uniform(-0.5, 6.0, 3)
             assert np.array_equal([orc.tone(kind, v) for v in rgb], orc.ref_tone(kind, rgb))
+
+
+def test_perlin_time_evolution_matches_reference():
+    """PerlinNoiseGeneratorWithTime::timeChanged (algorithms.cpp:57-77) along the driver's clock."""
+    from raytracer_amd import hip
+    _, G0 = orc.ref_perlin_tables(256)
+    Ga, Gb, Gc = G0.copy(), G0.copy(), G0.copy()
+    ca, cb = hip.PerlinClockC(), hip.PerlinClockC()
+    count = stage = 0
+    stime = prev = 0.0
+    t = 0.0
+    for _ in range(20):
+        orc.perlin_time_changed(ca, prev, t, Ga)
+        hip.perlin_time_changed(cb, prev, t, Gb)
+        count, stage, stime = orc.ref_perlin_time_changed(count, stage, stime, prev, t, Gc)
+        assert (ca.count, ca.stage, ca.stime) == (count, stage, stime) == (cb.count, cb.stage, cb.stime)
+        assert np.array_equal(Ga, Gc) and np.array_equal(Gb, Gc)
+        prev, t = t, t + 0.015
+    assert stage == 4 and not np.array_equal(Gc, G0) and np.allclose(np.linalg.norm(Gc, axis=1), 1.0)
