@@ -583,15 +583,28 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
     if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
     if (total_items == 0) return 0;
     const uint64_t max_push = (uint64_t)s->max_push;
-    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", 16u << 20);       // rays per round: large rounds keep the persistent grid
-                                                                     // busy (20 and more rays per lane) and cost only stack memory
+    // Rays per round.  Large rounds keep the persistent grid busy and mean fewer launches (fewer
+    // launch tails); they cost only stack memory, so by default the four stacks take a little over
+    // half of the device memory that is free, up to 64 Mi rays a round (37 GB a stack for two pushes
+    // per ray on a 288 GB part).  RT_WAVEFRONT_RAYS overrides.
+    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", 0);
+    if (target == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t held = 0;
+        for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) held += s->stack[c][k].cap * (RAY_FIELDS + 2) * sizeof(uint64_t);
+        const double budget = 0.55 * ((double)free_b + (double)held);
+        const double per_ray = 4.0 * (double)(max_push + 3) * (RAY_FIELDS + 2) * sizeof(uint64_t);
+        target = (uint64_t)(budget / per_ray) & ~((1ull << 20) - 1);
+        if (target > (64ull << 20)) target = 64ull << 20;
+        if (target < (1ull << 20)) target = 1ull << 20;
+    }
     if (target > total_items * max_push) target = total_items * max_push;
     if (target < RT_BLOCK) target = RT_BLOCK;
     uint64_t cap = target * (max_push + 3);
     while (cap >= 0xFFFFFFF0ull && target > (1u << 20)) { target >>= 1; cap = target * (max_push + 3); }
     if (cap >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
-    // the stacks are sized for a large part (4 x 9.4 GB for two pushes per ray); on a device with
-    // less free memory fall back to smaller rounds rather than fail
+    // on a device with less free memory than that fall back to smaller rounds rather than fail
     for (;;) {
         const int rc = ensure_stacks(s, cap, st);
         if (rc == 0) break;
