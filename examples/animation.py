@@ -52,7 +52,7 @@ def main():
     frames = render_frames(render_frame, a.frames, rank, world)
     if rank == 0:
         os.makedirs(a.out, exist_ok=True)
-        with hip.AviWriter(os.path.join(a.out, "anim.avi"), a.width, a.height, 15.0) as avi:
+        with hip.AviWriter(os.path.join(a.out, "anim.avi"), a.width, a.height, 15.0, mjpg_quality=95) as avi:
             for f, img in enumerate(frames):
                 hip.save_bmp(img, os.path.join(a.out, f"frame_{f:03d}.bmp"))
                 avi.add(img)

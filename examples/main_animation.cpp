@@ -2,8 +2,8 @@
 // per step, scene->setTime(time) before each render) written against include/rt_scene.hpp with
 // the reference's animated classes: a ChangeFovCamera (camera.cpp:74-94) and a MovableFaceLight
 // (light.cpp:87-107) over Phong / mirror / glass spheres.  Frames are written as BMP files
-// <prefix>NNN.bmp and, as in the reference, into <prefix>anim.avi through AviSaver (uncompressed
-// here; the reference's goes through OpenCV's MJPG encoder).
+// <prefix>NNN.bmp and, as in the reference, into <prefix>anim.avi through AviSaver (Motion-JPEG
+// by the library's own encoder; the reference's goes through OpenCV's).
 //   usage: main_animation [width height n frames prefix]   (defaults 160 120 2 8 frame_)
 #include <cstdio>
 #include <cstdlib>

@@ -263,12 +263,15 @@ int rt_resolve_tone_bgr8_host(const double *radiance_sum, int width, int height,
 int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename);
 
 /* Video file for the animation loop -- AviSaver::Open / AddImg / Save (AviSaver.cpp:9-75, used by
- * main.cpp:76-101).  The reference hands its frames to OpenCV's MJPG encoder; this writer has no
- * codec: the same RIFF/AVI container with uncompressed 24-bit frames (bottom-up B,G,R rows, which
- * is the layout rt_resolve_bgr8 produces and AddImg receives).  rt_avi_close writes the index and
+ * main.cpp:76-101).  rt_avi_open: the RIFF/AVI container with uncompressed 24-bit frames
+ * (bottom-up B,G,R rows, which is the layout rt_resolve_bgr8 produces and AddImg receives).  rt_avi_close writes the index and
  * the final sizes; a file that was not closed is not playable. */
 typedef struct rt_avi rt_avi;
 int rt_avi_open(const char *path, int width, int height, double fps, rt_avi **out);
+/* The same with Motion-JPEG frames, the fourcc AviSaver::Open asks OpenCV for (AviSaver.cpp:60):
+ * every frame a baseline JPEG (ITU-T T.81 Annex K tables, YCbCr 4:4:4) at `quality` 1..100.  Any
+ * MJPG decoder reads the file; its bytes are not those of OpenCV's encoder. */
+int rt_avi_open_mjpg(const char *path, int width, int height, double fps, int quality, rt_avi **out);
 int rt_avi_add_frame(rt_avi *avi, const uint8_t *bgr);
 int rt_avi_close(rt_avi *avi);
 

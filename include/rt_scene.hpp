@@ -458,8 +458,9 @@ private:
     uint64_t rays_[4] = {0, 0, 0, 0};
 };
 
-// AviSaver.h:6-24.  Frames go into an uncompressed AVI (the reference hands them to OpenCV's
-// MJPG encoder); with loop > 1 the frames are kept and written `loop` times by Save().
+// AviSaver.h:6-24.  Frames go into a Motion-JPEG AVI through the library's own encoder (the
+// reference hands them to OpenCV's); with loop > 1 the frames are kept and written `loop` times
+// by Save().
 class AviSaver {
 public:
     AviSaver() = default;
@@ -469,7 +470,7 @@ public:
     void Open(const std::string &path, int width, int height, double fps, unsigned int loop = 1)
     {
         if (avi_) { rt_avi_close(avi_); avi_ = nullptr; }
-        rt_avi_open(path.c_str(), width, height, fps, &avi_);
+        rt_avi_open_mjpg(path.c_str(), width, height, fps, 95, &avi_);      // fourcc MJPG as AviSaver.cpp:60; 95 = OpenCV's default JPEG quality
         width_ = width; height_ = height; loop_ = (int)loop;
     }
     bool isOpen() const { return avi_ != nullptr; }

@@ -905,7 +905,10 @@ struct rt_avi {
     int w = 0, h = 0;
     uint32_t stride = 0, frames = 0;
     double fps = 15;
-    long movi_start = 0;
+    int quality = 0;                       // 0: uncompressed frames; 1..100: Motion-JPEG at that quality
+    std::vector<uint32_t> sizes;           // payload bytes of every frame chunk
+    uint64_t movi_bytes = 4;               // 'movi' + chunks so far
+    uint32_t max_frame = 0;
 };
 namespace {
 void le32(FILE *f, uint32_t v) { unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)}; std::fwrite(b, 1, 4, f); }
@@ -915,8 +918,9 @@ void tag(FILE *f, const char *t) { std::fwrite(t, 1, 4, f); }
 void avi_header(rt_avi *a)
 {
     FILE *f = a->f;
-    const uint32_t frame_bytes = a->stride * (uint32_t)a->h, n = a->frames;
-    const uint32_t movi_size = 4 + n * (8 + frame_bytes), idx_size = n * 16;
+    const uint32_t n = a->frames, frame_bytes = a->quality ? a->max_frame : a->stride * (uint32_t)a->h;
+    const uint32_t movi_size = (uint32_t)a->movi_bytes, idx_size = n * 16;
+    const char *codec = a->quality ? "MJPG" : "DIB ";
     std::fseek(f, 0, SEEK_SET);
     tag(f, "RIFF"); le32(f, 4 + (8 + 4 + (8 + 56) + (8 + 4 + (8 + 56) + (8 + 40))) + (8 + movi_size) + (8 + idx_size)); tag(f, "AVI ");
     tag(f, "LIST"); le32(f, 4 + (8 + 56) + (8 + 4 + (8 + 56) + (8 + 40))); tag(f, "hdrl");
@@ -929,45 +933,208 @@ void avi_header(rt_avi *a)
     le32(f, 0); le32(f, 0); le32(f, 0); le32(f, 0);
     tag(f, "LIST"); le32(f, 4 + (8 + 56) + (8 + 40)); tag(f, "strl");
     tag(f, "strh"); le32(f, 56);
-    tag(f, "vids"); tag(f, "DIB "); le32(f, 0); le16(f, 0); le16(f, 0); le32(f, 0);
+    tag(f, "vids"); tag(f, codec); le32(f, 0); le16(f, 0); le16(f, 0); le32(f, 0);
     le32(f, 1000); le32(f, (uint32_t)(a->fps * 1000 + 0.5));   // scale, rate: rate / scale = frames per second
     le32(f, 0); le32(f, n); le32(f, frame_bytes); le32(f, 0xFFFFFFFFu); le32(f, 0);
     le16(f, 0); le16(f, 0); le16(f, (uint16_t)a->w); le16(f, (uint16_t)a->h);
     tag(f, "strf"); le32(f, 40);
-    le32(f, 40); le32(f, (uint32_t)a->w); le32(f, (uint32_t)a->h); le16(f, 1); le16(f, 24); le32(f, 0);   // BI_RGB, positive height: bottom-up
-    le32(f, frame_bytes); le32(f, 0); le32(f, 0); le32(f, 0); le32(f, 0);
+    le32(f, 40); le32(f, (uint32_t)a->w); le32(f, (uint32_t)a->h); le16(f, 1); le16(f, 24);
+    if (a->quality) tag(f, "MJPG"); else le32(f, 0);     // biCompression; BI_RGB with a positive height is bottom-up
+    le32(f, a->quality ? (uint32_t)a->w * a->h * 3u : frame_bytes); le32(f, 0); le32(f, 0); le32(f, 0); le32(f, 0);
     tag(f, "LIST"); le32(f, movi_size); tag(f, "movi");
-    a->movi_start = std::ftell(f);
+}
+
+// ---- baseline JPEG (ITU-T T.81: 8-bit, Huffman, the tables of Annex K, YCbCr 4:4:4, JFIF header)
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uint8_t kQLum[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                           18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQChr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                           99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kDcLumBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kDcChrBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kAcLumVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kAcChrBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kAcChrVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct HuffCode { uint16_t code[256]; uint8_t len[256]; };
+HuffCode make_codes(const uint8_t bits[16], const uint8_t *vals)
+{
+    HuffCode h;
+    std::memset(&h, 0, sizeof h);
+    uint16_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < bits[l - 1]; i++) { h.code[vals[k]] = code++; h.len[vals[k]] = (uint8_t)l; k++; }
+        code <<= 1;
+    }
+    return h;
+}
+struct BitSink {
+    std::vector<uint8_t> &out;
+    uint32_t acc = 0;
+    int n = 0;
+    void put(uint32_t code, int len)
+    {
+        acc = (acc << len) | (code & ((1u << len) - 1u));
+        n += len;
+        while (n >= 8) {
+            const uint8_t b = (uint8_t)(acc >> (n - 8));
+            out.push_back(b);
+            if (b == 0xFF) out.push_back(0);           // byte stuffing
+            n -= 8;
+        }
+    }
+    void flush() { if (n) put(0x7F, 8 - n); }           // pad with ones
+};
+// forward DCT of one 8x8 block (separable, direct form), quantise, entropy-code
+void encode_block(const float *px, const float *q, const double (*C)[8], int &dc_pred, const HuffCode &dc, const HuffCode &ac, BitSink &bs)
+{
+    double tmp[64], co[64];
+    for (int y = 0; y < 8; y++)
+        for (int u = 0; u < 8; u++) { double s = 0; for (int x = 0; x < 8; x++) s += px[8 * y + x] * C[u][x]; tmp[8 * y + u] = s; }
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) { double s = 0; for (int y = 0; y < 8; y++) s += tmp[8 * y + u] * C[v][y]; co[8 * v + u] = s; }
+    int zz[64];
+    for (int i = 0; i < 64; i++) zz[i] = (int)std::lround(co[kZigzag[i]] / q[kZigzag[i]]);
+    auto category = [](int v) { int a = v < 0 ? -v : v, c = 0; while (a) { c++; a >>= 1; } return c; };
+    const int diff = zz[0] - dc_pred;
+    dc_pred = zz[0];
+    int c = category(diff);
+    bs.put(dc.code[c], dc.len[c]);
+    if (c) bs.put((uint32_t)(diff < 0 ? diff - 1 : diff), c);
+    int run = 0;
+    for (int i = 1; i < 64; i++) {
+        if (zz[i] == 0) { run++; continue; }
+        while (run > 15) { bs.put(ac.code[0xF0], ac.len[0xF0]); run -= 16; }
+        c = category(zz[i]);
+        bs.put(ac.code[(run << 4) | c], ac.len[(run << 4) | c]);
+        bs.put((uint32_t)(zz[i] < 0 ? zz[i] - 1 : zz[i]), c);
+        run = 0;
+    }
+    if (run) bs.put(ac.code[0], ac.len[0]);            // end of block
+}
+// bgr: h rows of w pixels, bottom row first (the layout of rt_resolve_bgr8) -> a JFIF stream, top row first
+void encode_jpeg(const uint8_t *bgr, int w, int h, int quality, std::vector<uint8_t> &out)
+{
+    static const HuffCode dcl = make_codes(kDcLumBits, kDcVals), dcc = make_codes(kDcChrBits, kDcVals);
+    static const HuffCode acl = make_codes(kAcLumBits, kAcLumVals), acc = make_codes(kAcChrBits, kAcChrVals);
+    double C[8][8];
+    for (int u = 0; u < 8; u++)
+        for (int x = 0; x < 8; x++) C[u][x] = (u ? 0.5 : 0.35355339059327373) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16);
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;   // the usual quality scaling of the Annex K tables
+    uint8_t qt[2][64];
+    float qf[2][64];
+    for (int t = 0; t < 2; t++)
+        for (int i = 0; i < 64; i++) {
+            int v = ((t ? kQChr[i] : kQLum[i]) * scale + 50) / 100;
+            v = v < 1 ? 1 : (v > 255 ? 255 : v);
+            qt[t][i] = (uint8_t)v; qf[t][i] = (float)v;
+        }
+    out.clear();
+    auto be16 = [&](int v) { out.push_back((uint8_t)(v >> 8)); out.push_back((uint8_t)v); };
+    auto marker = [&](int m) { out.push_back(0xFF); out.push_back((uint8_t)m); };
+    marker(0xD8);
+    marker(0xE0); be16(16); for (char ch : {'J', 'F', 'I', 'F', '\0'}) out.push_back((uint8_t)ch); out.push_back(1); out.push_back(1); out.push_back(0); be16(1); be16(1); out.push_back(0); out.push_back(0);
+    for (int t = 0; t < 2; t++) { marker(0xDB); be16(67); out.push_back((uint8_t)t); for (int i = 0; i < 64; i++) out.push_back(qt[t][kZigzag[i]]); }
+    marker(0xC0); be16(17); out.push_back(8); be16(h); be16(w); out.push_back(3);
+    for (int c = 0; c < 3; c++) { out.push_back((uint8_t)(c + 1)); out.push_back(0x11); out.push_back(c ? 1 : 0); }
+    auto dht = [&](int cls_id, const uint8_t bits[16], const uint8_t *vals, int nvals) {
+        marker(0xC4); be16(19 + nvals); out.push_back((uint8_t)cls_id);
+        for (int i = 0; i < 16; i++) out.push_back(bits[i]);
+        for (int i = 0; i < nvals; i++) out.push_back(vals[i]);
+    };
+    dht(0x00, kDcLumBits, kDcVals, 12); dht(0x10, kAcLumBits, kAcLumVals, 162);
+    dht(0x01, kDcChrBits, kDcVals, 12); dht(0x11, kAcChrBits, kAcChrVals, 162);
+    marker(0xDA); be16(12); out.push_back(3);
+    out.push_back(1); out.push_back(0x00); out.push_back(2); out.push_back(0x11); out.push_back(3); out.push_back(0x11);
+    out.push_back(0); out.push_back(63); out.push_back(0);
+    BitSink bs{out};
+    int pred[3] = {0, 0, 0};
+    float blk[3][64];
+    for (int by = 0; by < h; by += 8)
+        for (int bx = 0; bx < w; bx += 8) {
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) {
+                    const int yy = by + y < h ? by + y : h - 1, xx = bx + x < w ? bx + x : w - 1;     // edge blocks repeat the last row / column
+                    const uint8_t *p = bgr + ((size_t)(h - 1 - yy) * w + xx) * 3;
+                    const float b = p[0], g = p[1], r = p[2];
+                    blk[0][8 * y + x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+                    blk[1][8 * y + x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+                    blk[2][8 * y + x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+                }
+            encode_block(blk[0], qf[0], C, pred[0], dcl, acl, bs);
+            encode_block(blk[1], qf[1], C, pred[1], dcc, acc, bs);
+            encode_block(blk[2], qf[1], C, pred[2], dcc, acc, bs);
+        }
+    bs.flush();
+    marker(0xD9);
+}
+
+int avi_open(const char *path, int width, int height, double fps, int quality, rt_avi **out, const char *who)
+{
+    if (!path || !out) return fail(std::string(who) + ": null argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || !(fps > 0)) return fail(std::string(who) + ": bad size or frame rate");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(std::string(who) + ": cannot open " + path);
+    rt_avi *a = new rt_avi;
+    a->f = f; a->w = width; a->h = height; a->fps = fps; a->quality = quality;
+    a->stride = ((uint32_t)width * 3u + 3u) & ~3u;
+    avi_header(a);
+    *out = a;
+    return 0;
 }
 }
 extern "C" {
 
 int rt_avi_open(const char *path, int width, int height, double fps, rt_avi **out)
 {
-    if (!path || !out) return fail("rt_avi_open: null argument");
-    *out = nullptr;
-    if (width <= 0 || height <= 0 || width > 65535 || height > 65535 || !(fps > 0)) return fail("rt_avi_open: bad size or frame rate");
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return fail(std::string("rt_avi_open: cannot open ") + path);
-    rt_avi *a = new rt_avi;
-    a->f = f; a->w = width; a->h = height; a->fps = fps;
-    a->stride = ((uint32_t)width * 3u + 3u) & ~3u;
-    avi_header(a);
-    *out = a;
-    return 0;
+    return avi_open(path, width, height, fps, 0, out, "rt_avi_open");
+}
+
+int rt_avi_open_mjpg(const char *path, int width, int height, double fps, int quality, rt_avi **out)
+{
+    if (quality < 1 || quality > 100) return fail("rt_avi_open_mjpg: quality must be in [1,100]");
+    return avi_open(path, width, height, fps, quality, out, "rt_avi_open_mjpg");
 }
 
 int rt_avi_add_frame(rt_avi *a, const uint8_t *bgr)
 {
     if (!a || !a->f || !bgr) return fail("rt_avi_add_frame: null argument");
-    const uint64_t frame_bytes = (uint64_t)a->stride * a->h;
-    if ((a->frames + 1ull) * (frame_bytes + 24) > 0xF0000000ull) return fail("rt_avi_add_frame: file would exceed the 4 GB RIFF limit");
-    tag(a->f, "00db"); le32(a->f, (uint32_t)frame_bytes);
-    const unsigned char zero[4] = {0, 0, 0, 0};
-    for (int y = 0; y < a->h; y++) {
-        if (std::fwrite(bgr + (size_t)y * a->w * 3, 1, (size_t)a->w * 3, a->f) != (size_t)a->w * 3) return fail("rt_avi_add_frame: write failed");
-        std::fwrite(zero, 1, a->stride - (uint32_t)a->w * 3u, a->f);
+    std::vector<uint8_t> jpg;
+    uint32_t bytes = a->stride * (uint32_t)a->h;
+    if (a->quality) { encode_jpeg(bgr, a->w, a->h, a->quality, jpg); bytes = (uint32_t)jpg.size(); }
+    const uint32_t padded = bytes + (bytes & 1u);
+    if (a->movi_bytes + padded + 8 + 16ull * (a->frames + 1) > 0xF0000000ull) return fail("rt_avi_add_frame: file would exceed the 4 GB RIFF limit");
+    tag(a->f, a->quality ? "00dc" : "00db"); le32(a->f, bytes);
+    if (a->quality) {
+        if (std::fwrite(jpg.data(), 1, bytes, a->f) != bytes) return fail("rt_avi_add_frame: write failed");
+        if (bytes & 1u) std::fputc(0, a->f);
+    } else {
+        const unsigned char zero[4] = {0, 0, 0, 0};
+        for (int y = 0; y < a->h; y++) {
+            if (std::fwrite(bgr + (size_t)y * a->w * 3, 1, (size_t)a->w * 3, a->f) != (size_t)a->w * 3) return fail("rt_avi_add_frame: write failed");
+            std::fwrite(zero, 1, a->stride - (uint32_t)a->w * 3u, a->f);
+        }
     }
+    a->sizes.push_back(bytes);
+    a->movi_bytes += 8 + padded;
+    if (bytes > a->max_frame) a->max_frame = bytes;
     a->frames++;
     return 0;
 }
@@ -977,9 +1144,12 @@ int rt_avi_close(rt_avi *a)
     if (!a) return 0;
     int rc = 0;
     if (a->f) {
-        const uint32_t frame_bytes = a->stride * (uint32_t)a->h;
         tag(a->f, "idx1"); le32(a->f, a->frames * 16);
-        for (uint32_t i = 0; i < a->frames; i++) { tag(a->f, "00db"); le32(a->f, 0x10); le32(a->f, 4 + i * (8 + frame_bytes)); le32(a->f, frame_bytes); }
+        uint32_t off = 4;
+        for (uint32_t i = 0; i < a->frames; i++) {
+            tag(a->f, a->quality ? "00dc" : "00db"); le32(a->f, 0x10); le32(a->f, off); le32(a->f, a->sizes[i]);
+            off += 8 + a->sizes[i] + (a->sizes[i] & 1u);
+        }
         avi_header(a);
         if (std::fclose(a->f) != 0) rc = fail("rt_avi_close: close failed");
     }

@@ -23,7 +23,7 @@ EXPORTS = (
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
-    "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_add_frame", "rt_avi_close",
+    "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_open_mjpg", "rt_avi_add_frame", "rt_avi_close",
     "rt_perlin_time_changed", "rt_scene_set_perlin",
 )
 
@@ -71,6 +71,7 @@ def lib():
     L.rt_resolve_tone_bgr8.argtypes = [_vp, _int, _int, _int, _int, _vp, _vp]
     L.rt_resolve_tone_bgr8_host.argtypes = [_vp, _int, _int, _int, _int, _vp]
     L.rt_avi_open.argtypes = [C.c_char_p, _int, _int, _dbl, C.POINTER(_vp)]
+    L.rt_avi_open_mjpg.argtypes = [C.c_char_p, _int, _int, _dbl, _int, C.POINTER(_vp)]
     L.rt_avi_add_frame.argtypes = [_vp, _vp]
     L.rt_avi_close.argtypes = [_vp]
     L.rt_perlin_time_changed.argtypes = [C.POINTER(PerlinClockC), _dbl, _dbl, _int, _vp]
@@ -164,10 +165,14 @@ class AviWriter:
     """AviSaver (AviSaver.cpp:9-75) without a codec: uncompressed frames in an AVI container.
     Frames are (h, w, 3) uint8 arrays in the layout of resolve_bgr8 (row 0 = bottom, B,G,R)."""
 
-    def __init__(self, path, width, height, fps=15.0):
+    def __init__(self, path, width, height, fps=15.0, mjpg_quality=0):
+        """mjpg_quality 0: uncompressed frames; 1..100: Motion-JPEG (the fourcc AviSaver asks for)."""
         self._h = _vp()
         self.shape = (height, width, 3)
-        _chk(lib().rt_avi_open(os.fsencode(path), width, height, float(fps), C.byref(self._h)), "rt_avi_open")
+        if mjpg_quality:
+            _chk(lib().rt_avi_open_mjpg(os.fsencode(path), width, height, float(fps), int(mjpg_quality), C.byref(self._h)), "rt_avi_open_mjpg")
+        else:
+            _chk(lib().rt_avi_open(os.fsencode(path), width, height, float(fps), C.byref(self._h)), "rt_avi_open")
 
     def add(self, bgr):
         a = np.ascontiguousarray(bgr, np.uint8)

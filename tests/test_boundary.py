@@ -229,3 +229,41 @@ def test_avi_container_round_trip(tmp_path):
     assert pos == moff + msize and isize == 16 * N
     with pytest.raises(hip.RtError):
         hip.AviWriter(str(tmp_path / "no_such_dir" / "b.avi"), W, H)
+
+
+def test_mjpg_avi_frames_decode(tmp_path):
+    """rt_avi_open_mjpg: every frame a baseline JPEG inside the AVI container; the frames are
+    pulled out of the 'movi' list and decoded with an independent decoder (Pillow)."""
+    import io
+    import struct
+    Image = pytest.importorskip("PIL.Image")
+    W, H, N = 83, 61, 3                                    # not multiples of 8: edge blocks
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    for k in range(N):
+        img = np.zeros((H, W, 3), np.uint8)               # bottom-up B,G,R as resolve_bgr8 gives it
+        img[..., 0] = (xx * 3 + 20 * k) % 256
+        img[..., 1] = (yy * 4) % 256
+        img[..., 2] = ((xx - 40) ** 2 + (yy - 30 - 5 * k) ** 2 < 300) * 220
+        frames.append(img)
+    f = str(tmp_path / "m.avi")
+    with hip.AviWriter(f, W, H, 15.0, mjpg_quality=92) as avi:
+        for fr in frames:
+            avi.add(fr)
+    raw = open(f, "rb").read()
+    assert raw[:4] == b"RIFF" and struct.unpack_from("<I", raw, 4)[0] == len(raw) - 8
+    assert raw.count(b"vidsMJPG") == 1 and b"00dc" in raw
+    movi = raw.index(b"movi")
+    idx = raw.rindex(b"idx1")
+    assert struct.unpack_from("<I", raw, idx + 4)[0] == 16 * N
+    for k in range(N):
+        ck, fl, off, sz = struct.unpack_from("<4sIII", raw, idx + 8 + 16 * k)
+        assert ck == b"00dc" and raw[movi + off:movi + off + 4] == b"00dc"
+        jpg = raw[movi + off + 8:movi + off + 8 + sz]
+        assert jpg[:2] == b"\xff\xd8" and jpg[-2:] == b"\xff\xd9"
+        dec = np.asarray(Image.open(io.BytesIO(jpg)).convert("RGB")).astype(float)       # top-down R,G,B
+        src = frames[k][::-1, :, ::-1].astype(float)
+        assert dec.shape == src.shape
+        psnr = 10 * np.log10(255.0 ** 2 / ((dec - src) ** 2).mean())
+        assert psnr > 30, psnr
+    assert len(raw) < N * W * H * 3                                                      # it does compress

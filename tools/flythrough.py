@@ -87,7 +87,7 @@ def main():
     if rank == 0:
         if a.out:
             os.makedirs(a.out, exist_ok=True)
-            with hip.AviWriter(os.path.join(a.out, "flythrough.avi"), W, H, 15.0) as avi:
+            with hip.AviWriter(os.path.join(a.out, "flythrough.avi"), W, H, 15.0, mjpg_quality=95) as avi:
                 for fr in frames:
                     avi.add(fr)
             hip.save_bmp(frames[len(frames) // 3], os.path.join(a.out, "frame.bmp"))
