@@ -506,6 +506,10 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
     __shared__ double run_bt1[BLOCK];        // upper end of the window of the lane's current primitive run
+    // the lane's ray in single precision (see RayF): formed once whenever T.e / T.d change and read
+    // back by every triangle step, which is cheaper than converting it again each step
+    __shared__ float4 rayf[2][BLOCK];
+#define RT_RAYF_PUT() { const RayF q_ = ray_single(T.e, T.d); rayf[0][tid] = make_float4(q_.ex, q_.ey, q_.ez, q_.inv_dd); rayf[1][tid] = make_float4(q_.dx, q_.dy, q_.dz, q_.slack); }
     TravState T = {};
     TriReg R = {};
     LeafSphere Q[4] = {};
@@ -544,6 +548,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 src.reload(T.item, T.e, T.d);
                 T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
                 T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                RT_RAYF_PUT()
             }
             // Octree::hit's verdict (octree.cpp:371-375)
             if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
@@ -581,6 +586,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #endif
                         T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
                         T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                        RT_RAYF_PUT()
                         mode = TM_OBJ;
                     } else {
                         Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0;
@@ -657,6 +663,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         T.d = T.d * inv;
                         T.fast = S.regular && dir_is_regular(T.d) && org_is_regular(T.e);
                         T.r = T.fast ? mk(1.0 / T.d.x, 1.0 / T.d.y, 1.0 / T.d.z) : mk(0, 0, 0);
+                        RT_RAYF_PUT()
                         T.oi = o | RT_OI_LOCAL;
                         T.root = head.z; T.cur = head.z; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS; mode = TM_NODE;
                     }
@@ -732,7 +739,8 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     }
                     // 2. pre-test the next four records, unless earlier ones still wait for their turn
                     if (T.pend == 0u && T.k < T.kend) {
-                        const RayF rf = ray_single(T.e, T.d);
+                        RayF rf;
+                        { const float4 a_ = rayf[0][tid], b_ = rayf[1][tid]; rf.ex = a_.x; rf.ey = a_.y; rf.ez = a_.z; rf.inv_dd = a_.w; rf.dx = b_.x; rf.dy = b_.y; rf.dz = b_.z; rf.slack = b_.w; }
                         const uint32_t left = T.kend - T.k, take = left < 4u ? left : 4u;
                         uint32_t m = 0;
 #pragma unroll
