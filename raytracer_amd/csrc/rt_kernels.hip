@@ -458,13 +458,13 @@ __device__ __forceinline__ bool sph_pass(const LeafSphere &s, const RayF &r)
     return !(perp2 > bound);
 }
 // A lane that has just opened a triangle run loads the spheres of its first four records (a
-// run shorter than four repeats its last record; the repeats are masked out when tested).
+// run shorter than four reads into the records that follow it, which are masked out when tested;
+// the array ends with four spare records).
 __device__ __forceinline__ void run_open(const DevScene &S, TravState &T, LeafSphere (&Q)[4])
 {
     const LeafSphere *P = S.leaf_sph + T.k;
-    const uint32_t last = T.kend - T.k - 1u;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + (i < last ? i : last));
+    for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + i);
     T.pend = 0; T.cand = RT_MISS;
 }
 // A voxel of an implicit surface (record with LEAF_VOXEL in its id: v0 / e1 = lower / upper
@@ -751,11 +751,11 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4
                         c.prim += take;
 #endif
-                        // the spheres of the four records after these (clamped to the run's last record)
-                        const uint32_t last = T.kend > T.k ? T.kend - T.k - 1u : 0u;
-                        const LeafSphere *P = S.leaf_sph + (T.kend > T.k ? T.k : T.kend - 1u);
+                        // the spheres of the four records after these (past the run's end they belong to
+                        // other runs, or are the array's spare records, and are masked out when tested)
+                        const LeafSphere *P = S.leaf_sph + T.k;
 #pragma unroll
-                        for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + (i < last ? i : last));
+                        for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + i);
                     }
                     // 3. request the first waiting record (candidates are tested in list order, so
                     //    "the last equal hit wins", octree.cpp:31, is kept)
