@@ -425,7 +425,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
     std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
     // four spare records at the end: the kernels fetch spheres four at a time without clamping
-    std::vector<LeafSphere> leaf_sph(leaf_tris.size() + 4, LeafSphere{0.0f, 0.0f, 0.0f, 0.0f});
+    std::vector<LeafSphere> leaf_sph(leaf_tris.size() + 8, LeafSphere{0.0f, 0.0f, 0.0f, 0.0f});
     for (size_t i = 0; i < leaf_tris.size(); i++)
         leaf_sph[i] = (leaf_tris[i].id & LEAF_VOXEL) ? make_voxel_sphere(leaf_tris[i]) : make_leaf_sphere(leaf_tris[i]);
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;

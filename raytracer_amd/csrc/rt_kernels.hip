@@ -236,6 +236,19 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 // appear in the slab arithmetic, so fmin / fmax equal std::min / std::max.  Otherwise true
 // divisions and the literal comparison forms are used (zero components give the +-inf / NaN
 // cases of hitBox, algorithms.h:208-236).
+// the closest-hit kernels are held to three waves per SIMD (168 VGPRs): left alone the register
+// allocator takes a few more and drops to two
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 3
+#endif
+#define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES)))
+// records whose spheres one triangle step tests
+#ifndef RT_PRE
+#define RT_PRE 7
+#endif
+#ifndef RT_WT
+#define RT_WT 8
+#endif
 enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 5 };
 // flag in TravState::oi while the lane's ray is expressed in an implicit surface's own frame
 #define RT_OI_LOCAL 0x40000000
@@ -460,11 +473,11 @@ __device__ __forceinline__ bool sph_pass(const LeafSphere &s, const RayF &r)
 // A lane that has just opened a triangle run loads the spheres of its first four records (a
 // run shorter than four reads into the records that follow it, which are masked out when tested;
 // the array ends with four spare records).
-__device__ __forceinline__ void run_open(const DevScene &S, TravState &T, LeafSphere (&Q)[4])
+__device__ __forceinline__ void run_open(const DevScene &S, TravState &T, LeafSphere (&Q)[RT_PRE])
 {
     const LeafSphere *P = S.leaf_sph + T.k;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + i);
+    for (uint32_t i = 0; i < RT_PRE; i++) Q[i] = sph_load(P + i);
     T.pend = 0; T.cand = RT_MISS;
 }
 // A voxel of an implicit surface (record with LEAF_VOXEL in its id: v0 / e1 = lower / upper
@@ -512,7 +525,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #define RT_RAYF_PUT() { const RayF q_ = ray_single(T.e, T.d); rayf[0][tid] = make_float4(q_.ex, q_.ey, q_.ez, q_.inv_dd); rayf[1][tid] = make_float4(q_.dx, q_.dy, q_.dz, q_.slack); }
     TravState T = {};
     TriReg R = {};
-    LeafSphere Q[4] = {};
+    LeafSphere Q[RT_PRE] = {};
     int mode = TM_FETCH;
     // rays are handed to a wave in batches of 64 .. batch_max: a quarter of an even share of what is left
     const uint32_t nwaves = gridDim.x * (BLOCK / 64);
@@ -692,7 +705,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
             const unsigned long long mN = __ballot(mode == TM_NODE || mode == TM_POP);
             const unsigned long long mT = __ballot(mode == TM_TRI);
             if ((mO | mN | mT) == 0ull) { finished = true; break; }
-            const int nO = __popcll(mO) * RT_WO, nN = __popcll(mN) * RT_WN, nT = __popcll(mT) * 8;
+            const int nO = __popcll(mO) * RT_WO, nN = __popcll(mN) * RT_WN, nT = __popcll(mT) * RT_WT;
             if (nO != 0 && nO >= nN && nO >= nT) break;
             if (nN != 0 && nN >= nT) {
                 // -------------------------------------------------------- node step
@@ -741,10 +754,10 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     if (T.pend == 0u && T.k < T.kend) {
                         RayF rf;
                         { const float4 a_ = rayf[0][tid], b_ = rayf[1][tid]; rf.ex = a_.x; rf.ey = a_.y; rf.ez = a_.z; rf.inv_dd = a_.w; rf.dx = b_.x; rf.dy = b_.y; rf.dz = b_.z; rf.slack = b_.w; }
-                        const uint32_t left = T.kend - T.k, take = left < 4u ? left : 4u;
+                        const uint32_t left = T.kend - T.k, take = left < (uint32_t)RT_PRE ? left : (uint32_t)RT_PRE;
                         uint32_t m = 0;
 #pragma unroll
-                        for (uint32_t i = 0; i < 4; i++) m |= sph_pass(Q[i], rf) ? 1u << i : 0u;
+                        for (uint32_t i = 0; i < RT_PRE; i++) m |= sph_pass(Q[i], rf) ? 1u << i : 0u;
                         T.pend = m & ((1u << take) - 1u);
                         T.pbase = T.k;
                         T.k += take;
@@ -755,7 +768,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         // other runs, or are the array's spare records, and are masked out when tested)
                         const LeafSphere *P = S.leaf_sph + T.k;
 #pragma unroll
-                        for (uint32_t i = 0; i < 4; i++) Q[i] = sph_load(P + i);
+                        for (uint32_t i = 0; i < RT_PRE; i++) Q[i] = sph_load(P + i);
                     }
                     // 3. request the first waiting record (candidates are tested in list order, so
                     //    "the last equal hit wins", octree.cpp:31, is kept)
@@ -770,7 +783,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
                     }
                 }
-                const int nT = __popcll(__ballot(mode == TM_TRI)) * 8;
+                const int nT = __popcll(__ballot(mode == TM_TRI)) * RT_WT;
                 if (nT == 0) break;
                 if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) * RT_WN >= nT) break;
                 if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) * RT_WO >= nT) break;
@@ -984,6 +997,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_ray_normals(DevScene S, const rt_r
     }
     normal[3ull * i] = nn.x; normal[3ull * i + 1] = nn.y; normal[3ull * i + 2] = nn.z;
 }
+RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(RaySrc src, uint32_t *next, uint64_t *counters)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
@@ -1013,6 +1027,7 @@ struct PrimarySrc {         // rt_trace_primary: one ray through every pixel cen
         if (tout) tout[pix] = hit ? hh.t : RT_INFINITE;
     }
 };
+RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(PrimarySrc src, uint32_t *next, uint64_t *counters)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
@@ -1225,6 +1240,7 @@ struct StackSrc {
         q.hit_id[slot] = hit ? (((uint64_t)(uint32_t)h.obj << 32) | h.prim) : ~0ull;
     }
 };
+RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next, uint32_t batch_max)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
