@@ -299,8 +299,9 @@ struct TravState {
     uint32_t k, kend, bprim;
     double bt0, tempt;
     bool leaf;
-    // pre-tested triangles waiting for the fp64 test: bit j of pend = record pbase + j;
-    // cand = the record requested in the previous step (RT_MISS: none)
+    // pre-tested triangles waiting for the fp64 test: bit j of pend = record pbase + j (a queue
+    // that several pre-test batches feed); cand = the record requested in the previous step
+    // (RT_MISS: none)
     uint32_t pend, pbase, cand;
 };
 
@@ -750,16 +751,18 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         if (R.id & LEAF_VOXEL) voxel_test(R, T, run_bt1[tid]); else tri_test(R, T);
                         T.cand = RT_MISS;
                     }
-                    // 2. pre-test the next four records, unless earlier ones still wait for their turn
-                    if (T.pend == 0u && T.k < T.kend) {
+                    // 2. pre-test the next records; the ones that pass queue up behind those that still
+                    //    wait for their fp64 test (bit j of pend = record pbase + j), as long as the
+                    //    32-bit queue has room
+                    if (T.pend == 0u) T.pbase = T.k;
+                    if (T.k < T.kend && T.k - T.pbase + (uint32_t)RT_PRE <= 32u) {
                         RayF rf;
                         { const float4 a_ = rayf[0][tid], b_ = rayf[1][tid]; rf.ex = a_.x; rf.ey = a_.y; rf.ez = a_.z; rf.inv_dd = a_.w; rf.dx = b_.x; rf.dy = b_.y; rf.dz = b_.z; rf.slack = b_.w; }
                         const uint32_t left = T.kend - T.k, take = left < (uint32_t)RT_PRE ? left : (uint32_t)RT_PRE;
                         uint32_t m = 0;
 #pragma unroll
                         for (uint32_t i = 0; i < RT_PRE; i++) m |= sph_pass(Q[i], rf) ? 1u << i : 0u;
-                        T.pend = m & ((1u << take) - 1u);
-                        T.pbase = T.k;
+                        T.pend |= (m & ((1u << take) - 1u)) << (T.k - T.pbase);
                         T.k += take;
 #if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4
                         c.prim += take;
