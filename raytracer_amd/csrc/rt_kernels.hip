@@ -543,6 +543,20 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #else
 #define RT_TICK(field)
 #endif
+    // The next node of the lane's depth-first walk: the next child, in sorted order, of the deepest
+    // open node that has one left (octree.cpp:349-368); with none left the octree is finished.
+    auto pop_now = [&]() {
+        mode = TM_OBJ;
+        while (T.sp > 0) {
+            const uint32_t w = stk[1][T.sp - 1][tid];
+            const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
+            if (pos == cnt) { T.sp--; continue; }
+            stk[1][T.sp - 1][tid] = w + (1u << 28);
+            T.cur = stk[0][T.sp - 1][tid] + ((w >> (3 * pos)) & 7u);
+            mode = TM_NODE;
+            break;
+        }
+    };
     for (;;) {
         // ---------------------------------------------------------------- object phase
         // Group::hit, Surface.cpp:160-181.  Lanes in OBJ mode have just finished the octree of
@@ -715,18 +729,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #elif RT_STEP_STATS == 2
                 if (mode == TM_NODE || mode == TM_POP) c.inner += 1;
 #endif
-                if (mode == TM_POP) {
-                    mode = TM_OBJ;                               // empty stack: this octree is finished
-                    while (T.sp > 0) {
-                        const uint32_t w = stk[1][T.sp - 1][tid];
-                        const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
-                        if (pos == cnt) { T.sp--; continue; }
-                        stk[1][T.sp - 1][tid] = w + (1u << 28);
-                        T.cur = stk[0][T.sp - 1][tid] + ((w >> (3 * pos)) & 7u);
-                        mode = TM_NODE;
-                        break;
-                    }
-                }
+                if (mode == TM_POP) pop_now();
                 const bool in = mode == TM_NODE;
                 if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, c); }
                 else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, c); }
