@@ -262,12 +262,49 @@ static LeafSphere make_leaf_sphere(const LeafTri &t)
 {
     double v[3][3], c[3];
     for (int k = 0; k < 3; k++) { v[0][k] = t.v0[k]; v[1][k] = t.v0[k] + t.e1[k]; v[2][k] = t.v0[k] + t.e2[k]; }
-    for (int k = 0; k < 3; k++) c[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
+    // the smallest sphere around the three vertices: centred on the middle of the longest edge when
+    // the opposite angle is right or obtuse, else on the circumcentre; if the circumcentre comes out
+    // badly (a nearly degenerate triangle) the centroid is used.  Whatever the centre, the radius is
+    // the largest vertex distance from it, so the sphere contains the triangle by construction.
+    double len2[3];
+    for (int i = 0; i < 3; i++) {
+        const double *p = v[(i + 1) % 3], *q = v[(i + 2) % 3];
+        len2[i] = (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]);
+    }
+    int lg = len2[0] >= len2[1] ? (len2[0] >= len2[2] ? 0 : 2) : (len2[1] >= len2[2] ? 1 : 2);
+    if (len2[lg] >= len2[(lg + 1) % 3] + len2[(lg + 2) % 3]) {
+        for (int k = 0; k < 3; k++) c[k] = (v[(lg + 1) % 3][k] + v[(lg + 2) % 3][k]) / 2;
+    } else {
+        // circumcentre = v0 + (|b|^2 (a x b) x a + |a|^2 b x (a x b)) / (2 |a x b|^2), a = e1, b = e2
+        const double *a = t.e1, *bb = t.e2;
+        const double n[3] = {a[1] * bb[2] - a[2] * bb[1], a[2] * bb[0] - a[0] * bb[2], a[0] * bb[1] - a[1] * bb[0]};
+        const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        const double a2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], b2 = bb[0] * bb[0] + bb[1] * bb[1] + bb[2] * bb[2];
+        const double nxa[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0]};
+        const double bxn[3] = {bb[1] * n[2] - bb[2] * n[1], bb[2] * n[0] - bb[0] * n[2], bb[0] * n[1] - bb[1] * n[0]};
+        bool ok = n2 > 0 && std::isfinite(n2);
+        for (int k = 0; k < 3 && ok; k++) {
+            c[k] = t.v0[k] + (b2 * nxa[k] + a2 * bxn[k]) / (2 * n2);
+            ok = std::isfinite(c[k]);
+        }
+        if (!ok) for (int k = 0; k < 3; k++) c[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
+    }
     double r2 = 0;
     for (int i = 0; i < 3; i++) {
         double d2 = 0;
         for (int k = 0; k < 3; k++) d2 += (v[i][k] - c[k]) * (v[i][k] - c[k]);
         if (!(d2 <= r2)) r2 = d2;
+    }
+    // a circumcentre far outside a sliver would make the sphere larger than the centroid's: keep the smaller
+    {
+        double g[3], rg2 = 0;
+        for (int k = 0; k < 3; k++) g[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
+        for (int i = 0; i < 3; i++) {
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) d2 += (v[i][k] - g[k]) * (v[i][k] - g[k]);
+            if (!(d2 <= rg2)) rg2 = d2;
+        }
+        if (rg2 < r2) { r2 = rg2; for (int k = 0; k < 3; k++) c[k] = g[k]; }
     }
     const double r = std::sqrt(r2) * (1.0 + 1e-5) + 4e-7 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
     LeafSphere s;
