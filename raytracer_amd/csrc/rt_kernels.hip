@@ -242,6 +242,13 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 #define RT_TRACE_WAVES 3
 #endif
 #define RT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(RT_TRACE_WAVES, RT_TRACE_WAVES)))
+// largest batch of rays a wave reserves at a time, for rays that reach a large octree and for the rest
+#ifndef RT_BATCH1
+#define RT_BATCH1 128
+#endif
+#ifndef RT_BATCH0
+#define RT_BATCH0 1024
+#endif
 // records whose spheres one triangle step tests
 #ifndef RT_PRE
 #define RT_PRE 7
@@ -1560,7 +1567,7 @@ hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const Wav
     StackSrc src = { A, q, base, count };
     hipError_t e = hipMemsetAsync(next, 0, 4, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next, ray_class ? 128u : 1024u);
+    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next, ray_class ? (uint32_t)RT_BATCH1 : (uint32_t)RT_BATCH0);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
