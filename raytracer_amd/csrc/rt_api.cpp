@@ -462,6 +462,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
     std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
     // four spare records at the end: the kernels fetch spheres four at a time without clamping
+    // geometric normals: Vec3::operator^ and normalize as the kernels' cross / norm evaluate them
+    std::vector<double> tri_normals(tris.size() / 3);
+    for (size_t i = 0; i < tris.size() / 9; i++) {
+        const double *l = &tris[9 * i + 3], *r = &tris[9 * i + 6];
+        const double n[3] = {l[1] * r[2] - r[1] * l[2], l[2] * r[0] - l[0] * r[2], l[0] * r[1] - r[0] * l[1]};
+        const double inv = 1 / std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        for (int k = 0; k < 3; k++) tri_normals[3 * i + k] = n[k] * inv;
+    }
     std::vector<LeafSphere> leaf_sph(leaf_tris.size() + 8, LeafSphere{0.0f, 0.0f, 0.0f, 0.0f});
     for (size_t i = 0; i < leaf_tris.size(); i++)
         leaf_sph[i] = (leaf_tris[i].id & LEAF_VOXEL) ? make_voxel_sphere(leaf_tris[i]) : make_leaf_sphere(leaf_tris[i]);
@@ -472,7 +480,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         e = upload(vec, dst);
         if (*dst) s->allocs.push_back(*dst);
     };
-    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tris, &p_tris); up(leaf_sph, &p_sph);
+    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tri_normals, &p_tris); up(leaf_sph, &p_sph);
     up(perlin_p, &p_pp); up(perlin_g, &p_pg);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
@@ -483,7 +491,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.nodes = (const FlatNode *)p_nodes;
     s->dev.leaf_tris = (const LeafTri *)p_idx;
     s->dev.leaf_sph = (const LeafSphere *)p_sph;
-    s->dev.tris = (const double *)p_tris;
+    s->dev.tri_normals = (const double *)p_tris;
     s->dev.perlin_p = (const int32_t *)p_pp;
     s->dev.perlin_g = (const double *)p_pg;
     s->dev.perlin_n = (int32_t)perlin_p.size();

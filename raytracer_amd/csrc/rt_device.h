@@ -38,7 +38,7 @@ struct DevScene {
     const FlatNode    *nodes;      // all meshes' nodes, 64-byte records
     const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
     const LeafSphere  *leaf_sph;   // one bounding sphere per leaf_tris record (same index)
-    const double      *tris;       // v0, e1, e2 (9 doubles) by global triangle index, for shading normals
+    const double      *tri_normals; // normalize(e1 ^ e2) (3 doubles) by global triangle index
     const int32_t     *perlin_p;   // Perlin permutation and unit vectors (perlin_n, 3 x perlin_n); null without Perlin materials
     const double      *perlin_g;
     int32_t nobjects;

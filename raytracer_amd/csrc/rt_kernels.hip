@@ -811,7 +811,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 }
 
 // Drawable::doAfterHit -> getRawNormal (Surface.cpp:228-231, 68-71; Surface.h:184,197,211);
-// a mesh hit takes the hit triangle's geometric normal.
+// a mesh hit takes the hit triangle's geometric normal (normalize(e1 ^ e2), formed once at upload).
 // ------------------------------------------------------------------ Perlin materials
 // algorithm::perlinNoise, algorithms.h:56-87
 // (a real call, not inlined: the Perlin materials are rare, and their code must not weigh on the
@@ -904,8 +904,7 @@ __device__ inline V3 raw_normal(const DevScene &S, const Hit &h, V3 p)
     if (o.type == RT_OBJ_GROUND) return mk(0, 1, 0);
     if (o.type == RT_OBJ_WALL_Z) return mk(0, 0, 1);
     if (o.type == RT_OBJ_WALL_X) return mk(1, 0, 0);
-    const double *tr = S.tris + 9ull * h.prim;
-    return norm(cross(ld3(tr + 3), ld3(tr + 6)));
+    return ld3(S.tri_normals + 3ull * h.prim);
 }
 // Node::getNormal, Surface.cpp:15-23: the material may adjust the raw normal
 __device__ inline V3 hit_normal(const DevScene &S, const Hit &h, V3 p)
