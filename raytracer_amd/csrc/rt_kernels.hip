@@ -1336,7 +1336,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         if (A.face_forward && dot(w, rd) > 0) w = -w;
         V3 u = norm(cross(fabs(w.x) > 0.1 ? mk(0, 1, 0) : mk(1, 0, 0), w));
         V3 v = cross(w, u);
-        dn = norm(((u * cos(r1)) * r2s + (v * sin(r1)) * r2s) + w * sqrt(1 - r2));
+        double sn, cs;
+        sincos(r1, &sn, &cs);                                               // one argument reduction for both
+        dn = norm(((u * cs) * r2s + (v * sn) * r2s) + w * sqrt(1 - r2));
         wn = norm(w);
         sum = sum + had(W, emission * Ed);
     }
