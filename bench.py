@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="image width = height")
     ap.add_argument("--spp-root", type=int, default=16, help="n of the n x n jitter table per GPU")
+    ap.add_argument("--workload", choices=["bunny", "atrium"], default="bunny",
+                    help="bunny: the single-GPU benchmark configuration (default); atrium: the Sponza-class scene "
+                         "(~262 k triangles, rectangular light) at 1920 x 1080, 128 spp per GPU unless --spp-root is given")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -104,11 +107,20 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    W = H = a.size
-    n = a.spp_root
-    m = a.spp_root * world                      # weak scaling: 256 samples per pixel per GPU
     seed = 1243                                 # the reference's srand value (scene.cpp:22)
-    desc, cam = scenes.bunny_cornell_scene()    # 69 564-triangle mesh, Cornell box of triangle meshes, sphere light
+    if a.workload == "atrium":
+        W, H = (1920, 1080) if a.size == 1024 else (a.size * 16 // 9, a.size)
+        n = a.spp_root
+        m = (8 if a.spp_root == 16 else a.spp_root) * world      # 128 spp per GPU: 1024 spp on 8 GPUs
+        desc, cam = scenes.atrium_scene()
+        label = "Sponza-class atrium"
+    else:
+        W = H = a.size
+        n = a.spp_root
+        m = a.spp_root * world                  # weak scaling: 256 samples per pixel per GPU
+        desc, cam = scenes.bunny_cornell_scene()    # 69 564-triangle mesh, Cornell box of triangle meshes, sphere light
+        label = "bunny-class mesh"
+    per_gpu = n * m // world
     ntris = sum(len(x) for x in desc.meshes)
     t0 = time.time()
     sc = hip.HipScene(desc)
@@ -174,7 +186,7 @@ def main():
         achieved_ops = ops_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and a.workload == "bunny":      # the counters were collected on the default workload
             try:
                 traffic = json.load(open(tfile)).get("bytes_per_trace_launch")
             except Exception:
@@ -190,9 +202,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"bunny-class mesh ({ntris} triangles) in a triangle Cornell box via octree (leaf capacity 128), "
-                                   f"{W}x{H} @ {n * n} spp per GPU ({n * m} spp total), sphere light, max depth 40 / roulette from 12",
-                       "width": W, "height": H, "spp_total": n * m, "spp_per_gpu": n * n, "triangles": ntris,
+            "config": {"workload": (f"{label} ({ntris} triangles) in a triangle Cornell box via octree (leaf capacity 128), " if a.workload == "bunny"
+                                    else f"{label} ({ntris} triangles, rectangular light) via octrees (leaf capacity 128), ")
+                                   + f"{W}x{H} @ {per_gpu} spp per GPU ({n * m} spp total), max depth 40 / roulette from 12",
+                       "width": W, "height": H, "spp_total": n * m, "spp_per_gpu": per_gpu, "triangles": ntris,
                        "parallelism": f"spp-partition x{world}, sum-reduce to rank 0"},
             "spp_per_s": n * m * steps / dt,
             "mpaths_per_s": paths_per_step * steps / dt / 1e6,
