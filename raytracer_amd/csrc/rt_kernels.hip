@@ -759,6 +759,9 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                     // 1. the fp64 test of the record requested in the previous step
                     if (T.cand != RT_MISS) {
                         if (R.id & LEAF_VOXEL) voxel_test(R, T, run_bt1[tid]); else tri_test(R, T);
+#if RT_STEP_STATS == 5
+                        c.rays += 1;                                 // records that reached the fp64 test
+#endif
                         T.cand = RT_MISS;
                     }
                     // 2. pre-test the next records; the ones that pass queue up behind those that still
