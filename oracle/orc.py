@@ -345,6 +345,8 @@ def ref():
         R.ref_perlin_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         R.ref_perlin_material.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _dp]
         R.ref_perlin_time_changed.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_void_p]
+        R.ref_change_fov_camera.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp]
+        R.ref_movable_face_light.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp]
         R.ref_tone.argtypes = [C.c_int, _dp, _dp]
         for f in ("ref_const_zero", "ref_const_infinite", "ref_const_pi"):
             getattr(R, f).restype = C.c_double
@@ -526,3 +528,15 @@ def ref_perlin_time_changed(count, stage, stime, prev_time, time, G):
     st = C.c_double(stime)
     ref().ref_perlin_time_changed(clk, C.byref(st), prev_time, time, len(G), _p(G))
     return clk[0], clk[1], st.value
+
+
+def ref_change_fov_camera(look_from, look_at, vup, vfov, aspect, time):
+    out = (C.c_double * 14)()
+    ref().ref_change_fov_camera(_d3(look_from), _d3(look_at), _d3(vup), vfov, aspect, time, out)
+    return np.array(out[:])
+
+
+def ref_movable_face_light(pos, normal, up, w, h, time, u, v):
+    a, b = (C.c_double * 3)(), (C.c_double * 3)()
+    ref().ref_movable_face_light(_d3(pos), _d3(normal), _d3(up), w, h, time, u, v, a, b)
+    return np.array(a[:]), np.array(b[:])

@@ -442,6 +442,29 @@ void ref_perlin_time_changed(int32_t clock[2], double *stime, double prev_time, 
     for (int i = 0; i < n; i++) st(G + 3 * i, algorithm::PerlinNoiseGenerator::G_[i]);
 }
 
+// ChangeFovCamera under RTObject::setTime (camera.cpp:74-94): out = e, llc, u, v, width, height (14 doubles)
+void ref_change_fov_camera(const double from[3], const double at[3], const double vup[3], double vfov, double aspect,
+                           double time, double out[14])
+{
+    ChangeFovCamera c(v3(from), v3(at), v3(vup), vfov, aspect);
+    c.setTime(time);
+    st(out, c.e_); st(out + 3, c.leftLowerCorner); st(out + 6, c.u_); st(out + 9, c.v_);
+    out[12] = c.width; out[13] = c.height;
+}
+// MovableFaceLight::getPosition at a time (light.cpp:87-107) with table entry (u, v): the sampled
+// point, and the light's own position after the move
+void ref_movable_face_light(const double pos[3], const double normal[3], const double up[3], double w, double h,
+                            double time, double u, double v, double out_sample[3], double out_pos[3])
+{
+    auto l = std::make_shared<MovableFaceLight>(v3(pos), v3(normal), v3(up), w, h, Color(1, 1, 1, 1), Color(1, 1, 1, 1), Color(1, 1, 1, 1));
+    l->setTime(time);
+    l->randomPairs_.assign(1, std::make_pair(u, v));
+    l->itIndex_ = 0;
+    Vec3 n; double p = 0;
+    Vec3 r = l->getPosition(nullptr, &n, &p);
+    st(out_sample, r); st(out_pos, l->pos_);
+}
+
 // RTObject::calRandom structure check (RTObject.cpp:46-69) cannot be run on glibc
 // (RAND_MAX + 1 overflows); only the table layout constants are exposed.
 double ref_const_zero(void) { return ZERO; }

@@ -190,6 +190,18 @@ def main():
     x = rr.uniform(-0.5, 6.0, (400, 3))
     np.savez_compressed(os.path.join(HERE, "tone.npz"), x=x, sigmoid=np.stack([orc.ref_tone(1, v) for v in x]),
                         sqrt=np.stack([orc.ref_tone(2, v) for v in x]))
+    # 11. ChangeFovCamera / MovableFaceLight under RTObject::setTime along the driver's clock
+    #     (camera.cpp:88-94, light.cpp:101-107, main.cpp:83)
+    cam = dict(look_from=(1, 2, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=40.0, aspect=1.5)
+    times, cams, lpos, lsample = [], [], [], []
+    tt = 0.0
+    for _ in range(140):
+        times.append(tt)
+        cams.append(orc.ref_change_fov_camera(time=tt, **cam))
+        smp, pos = orc.ref_movable_face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, tt, 0.3, 0.8)
+        lpos.append(pos); lsample.append(smp)
+        tt += 0.015
+    np.savez_compressed(os.path.join(HERE, "animation.npz"), times=np.array(times), cams=np.stack(cams), light_pos=np.stack(lpos), light_sample=np.stack(lsample))
     print("golden vectors written to", HERE)
 
 

@@ -159,6 +159,15 @@ def test_animated_camera_and_light_are_host_arithmetic_and_match_oracle():
         assert np.allclose(centre, a.look_at, atol=1e-12)
         t += 0.015
     l0 = scenes.face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, (.5, .5, .6))
+    # the same along the driver's clock against what the reference's own classes gave
+    with np.load(os.path.join(ROOT, "tests", "golden", "animation.npz")) as g:
+        for t, gc, gp, gs in zip(g["times"], g["cams"], g["light_pos"], g["light_sample"]):
+            c = hip.camera_change_fov(a0, float(t))
+            assert np.array_equal(np.array(list(c.e) + list(c.llc) + list(c.u) + list(c.v) + [c.width, c.height]), gc)
+            l = hip.light_move_face(l0, float(t))
+            assert np.array_equal(l["pos"], gp)
+            p, _, _ = orc.light_sample(orc.light_move_face(l0, float(t)), (0, 0, 0), 0.3, 0.8)
+            assert np.array_equal(p, gs)
     for t in (0.0, 0.015, 0.25, 0.5, 1.37, 2.0):
         a, b = hip.light_move_face(l0, t), orc.light_move_face(l0, t)
         assert a.tobytes() == b.tobytes()

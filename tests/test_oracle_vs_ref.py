@@ -224,3 +224,22 @@ def test_perlin_time_evolution_matches_reference():
         assert np.array_equal(Ga, Gc) and np.array_equal(Gb, Gc)
         prev, t = t, t + 0.015
     assert stage == 4 and not np.array_equal(Gc, G0) and np.allclose(np.linalg.norm(Gc, axis=1), 1.0)
+
+
+def test_animated_camera_and_light_match_reference():
+    """ChangeFovCamera::timeChanged (camera.cpp:88-94) and MovableFaceLight::getPosition
+    (light.cpp:101-107) under RTObject::setTime, along the driver's clock."""
+    cam = dict(look_from=(1, 2, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=40.0, aspect=1.5)
+    c0 = orc.camera_init(**cam)
+    l0 = scenes.face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, (.5, .5, .6))
+    t = 0.0
+    for _ in range(140):
+        c = orc.camera_change_fov(c0, t)
+        got = np.array(list(c.e) + list(c.llc) + list(c.u) + list(c.v) + [c.width, c.height])
+        assert np.array_equal(got, orc.ref_change_fov_camera(time=t, **cam))
+        l = orc.light_move_face(l0, t)
+        sample, pos = orc.ref_movable_face_light((-3, 6, 3), (0.4, -1, -0.3), (0, 0, 1), 2.5, 1.5, t, 0.3, 0.8)
+        assert np.array_equal(l["pos"], pos)
+        p, _, _ = orc.light_sample(l, (0, 0, 0), 0.3, 0.8)
+        assert np.array_equal(p, sample)
+        t += 0.015
