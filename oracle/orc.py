@@ -53,6 +53,7 @@ def lib():
         L.orc_perlin_material.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.orc_camera_init.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(CameraC)]
         L.orc_camera_get_ray.argtypes = [C.POINTER(CameraC), C.c_double, C.c_double, C.c_void_p]
+        L.orc_camera_get_ray_disk.argtypes = [C.POINTER(CameraC), C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_camera_change_fov.argtypes = [C.POINTER(CameraC), C.c_double, C.POINTER(CameraC)]
         L.orc_light_move_face.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_double, C.c_double,
@@ -228,6 +229,12 @@ def camera_get_ray(cam, s, t):
     return r[0]
 
 
+def camera_get_ray_disk(cam, s, t, x, y):
+    r = np.zeros(1, RAY_DT)
+    lib().orc_camera_get_ray_disk(C.byref(cam), float(s), float(t), float(x), float(y), _p(r))
+    return r[0]
+
+
 def resolve_bgr8(radiance_sum, spp, tone=0):
     h, w, _ = radiance_sum.shape
     a = np.ascontiguousarray(radiance_sum, np.float64)
@@ -347,6 +354,7 @@ def ref():
         R.ref_perlin_time_changed.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_void_p]
         R.ref_change_fov_camera.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp]
         R.ref_movable_face_light.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        R.ref_depth_camera_ray.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_uint, C.c_double, C.c_double, _dp, _dp]
         R.ref_tone.argtypes = [C.c_int, _dp, _dp]
         for f in ("ref_const_zero", "ref_const_infinite", "ref_const_pi"):
             getattr(R, f).restype = C.c_double
@@ -540,3 +548,9 @@ def ref_movable_face_light(pos, normal, up, w, h, time, u, v):
     a, b = (C.c_double * 3)(), (C.c_double * 3)()
     ref().ref_movable_face_light(_d3(pos), _d3(normal), _d3(up), w, h, time, u, v, a, b)
     return np.array(a[:]), np.array(b[:])
+
+
+def ref_depth_camera_ray(look_from, look_at, vup, vfov, aspect, aperture, seed, s, t):
+    ray, xy = (C.c_double * 6)(), (C.c_double * 2)()
+    ref().ref_depth_camera_ray(_d3(look_from), _d3(look_at), _d3(vup), vfov, aspect, aperture, seed, s, t, ray, xy)
+    return np.array(ray[:]), np.array(xy[:])

@@ -465,6 +465,20 @@ void ref_movable_face_light(const double pos[3], const double normal[3], const d
     st(out_sample, r); st(out_pos, l->pos_);
 }
 
+// DepthCamera::getRay (camera.cpp:62-72).  Its lens point comes from algorithm::randFromDisk
+// (rand()); the generator is seeded, the point drawn here, then seeded again so that getRay draws
+// the same one.  out = e, d; xy = the lens point.
+void ref_depth_camera_ray(const double from[3], const double at[3], const double vup[3], double vfov, double aspect, double aperture,
+                          unsigned seed, double s, double t, double ray[6], double xy[2])
+{
+    DepthCamera c(v3(from), v3(at), v3(vup), vfov, aspect, aperture);
+    srand(seed);
+    algorithm::randFromDisk(&xy[0], &xy[1]);
+    srand(seed);
+    Ray r = c.getRay((float)s, (float)t);
+    st(ray, r.e); st(ray + 3, r.d);
+}
+
 // RTObject::calRandom structure check (RTObject.cpp:46-69) cannot be run on glibc
 // (RAND_MAX + 1 overflows); only the table layout constants are exposed.
 double ref_const_zero(void) { return ZERO; }

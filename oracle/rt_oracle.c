@@ -1017,9 +1017,16 @@ void orc_light_move_face(const orc_light *origin, double time, orc_light *out)
 /* DepthCamera::getRay, camera.cpp:62-72: the origin moves on the lens disk (randFromDisk,
  * algorithms.h:30-35, drawn from the sample's own key), the film point stays */
 #define KEY_LENS 0x4c454e53ULL
-static ray_t camera_ray_lens(const orc_camera *c, float s, float t, uint64_t root_key)
+static ray_t camera_ray_disk(const orc_camera *c, float s, float t, double x, double y)
 {
     ray_t r;
+    r.e = vadd(vadd(v3p(c->e), vmul(v3p(c->u), x * c->aperture)), vmul(v3p(c->v), y * c->aperture));
+    v3 lookat = vadd(vadd(v3p(c->llc), vmul(vmul(v3p(c->u), s), c->width)), vmul(vmul(v3p(c->v), t), c->height));
+    r.d = vnorm(vsub(lookat, r.e));
+    return r;
+}
+static ray_t camera_ray_lens(const orc_camera *c, float s, float t, uint64_t root_key)
+{
     uint64_t key = orc_hash2(root_key, KEY_LENS);
     double x, y;
     uint32_t a = 0;
@@ -1028,10 +1035,13 @@ static ray_t camera_ray_lens(const orc_camera *c, float s, float t, uint64_t roo
         y = (draw(key, SLOT_DISK + 2 * a + 1) - 0.5) * 2;
         a++;
     } while (x * x + y * y >= 1.0);
-    r.e = vadd(vadd(v3p(c->e), vmul(v3p(c->u), x * c->aperture)), vmul(v3p(c->v), y * c->aperture));
-    v3 lookat = vadd(vadd(v3p(c->llc), vmul(vmul(v3p(c->u), s), c->width)), vmul(vmul(v3p(c->v), t), c->height));
-    r.d = vnorm(vsub(lookat, r.e));
-    return r;
+    return camera_ray_disk(c, s, t, x, y);
+}
+/* DepthCamera::getRay (camera.cpp:62-72) for a given point (x, y) of the unit disk */
+void orc_camera_get_ray_disk(const orc_camera *c, double s, double t, double x, double y, orc_ray *out)
+{
+    ray_t r = camera_ray_disk(c, (float)s, (float)t, x, y);
+    v3st(out->e, r.e); v3st(out->d, r.d);
 }
 static ray_t camera_ray(const orc_camera *c, float s, float t)
 {

@@ -161,6 +161,8 @@ void orc_camera_init(const double from[3], const double at[3], const double vup[
                      double vfov, double aspect, orc_camera *out);
 /* Camera::getRay, camera.cpp:24-31 (s,t rounded to float as in the reference signature) */
 void orc_camera_get_ray(const orc_camera *c, double s, double t, orc_ray *out);
+/* DepthCamera::getRay (camera.cpp:62-72) with the lens point (x, y) of the unit disk given */
+void orc_camera_get_ray_disk(const orc_camera *c, double s, double t, double x, double y, orc_ray *out);
 /* ChangeFovCamera::timeChanged (camera.cpp:88-94) applied to `origin`; MovableFaceLight::getPosition's
  * move of the light (light.cpp:101-107) applied to `origin` */
 void orc_camera_change_fov(const orc_camera *origin, double time, orc_camera *out);

@@ -243,3 +243,17 @@ def test_animated_camera_and_light_match_reference():
         p, _, _ = orc.light_sample(l, (0, 0, 0), 0.3, 0.8)
         assert np.array_equal(p, sample)
         t += 0.015
+
+
+def test_depth_camera_ray_matches_reference():
+    """DepthCamera::getRay (camera.cpp:62-72) for the lens point the reference's randFromDisk drew."""
+    cam = dict(look_from=(1, 2, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=40.0, aspect=1.5)
+    c = orc.camera_init(**cam)
+    c.aperture = 0.35
+    rng = np.random.default_rng(2)
+    for seed in range(200):
+        s, t = rng.uniform(0, 1, 2)
+        ray, xy = orc.ref_depth_camera_ray(aperture=0.35, seed=seed, s=s, t=t, **cam)
+        assert xy[0] ** 2 + xy[1] ** 2 < 1.0
+        r = orc.camera_get_ray_disk(c, s, t, xy[0], xy[1])
+        assert np.array_equal(np.concatenate([r["e"], r["d"]]), ray)
