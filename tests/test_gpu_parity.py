@@ -659,6 +659,28 @@ def test_benchmark_frame_full_size_properties():
     assert np.array_equal(k, k2) and np.abs(again - whole).max() <= 1e-9 * max(1.0, np.abs(whole).max())
 
 
+def test_atrium_scene_ids_and_radiance():
+    """The Sponza-class atrium (three octrees with inner nodes, rectangular light): tree shape and
+    primary ids / distances bit-exact at full detail, a small frame against the oracle."""
+    desc, cam = scenes.atrium_scene()
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    for i in range(len(desc.meshes)):
+        assert so.octree_stats(i) == sg.octree_stats(i)
+    c = hip.camera_init(**cam)
+    W, H = 160, 90
+    a1, b1, _ = so.trace_primary(c, W, H); a2, b2, _ = sg.trace_primary(c, W, H)
+    assert (a1 != MISS).mean() > 0.99
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    W, H, n = 64, 36, 2
+    prm = render_params(W, H, n, seed=1243)
+    i1, k1 = so.render(c, prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2)
+    assert (_rel(i1, i2) > PATH_RTOL).mean() <= 1e-3
+    assert np.sqrt((((i1 - i2) / (n * n)) ** 2).mean()) <= RMSE_TOL
+    assert i1.mean() > 0.0
+
+
 def test_perlin_tables_drift_with_time():
     """rt_scene_set_perlin: the generator's vectors after some frames of the driver's clock are
     patched into the uploaded scene; the frame equals the oracle's for a scene built with them."""
