@@ -237,35 +237,33 @@ int rt_scene_destroy(rt_scene *s)
     return 0;
 }
 
-// Bounding sphere of a voxel record for the same pre-test: the box's centre and half diagonal.
-static LeafSphere make_leaf_sphere(const LeafTri &t);
-static LeafSphere make_voxel_sphere(const LeafTri &t)
+// ---------------------------------------------------------------- pre-test spheres
+// Every record of a node's run gets a bounding sphere for the kernels' single-precision pre-test,
+// expressed in the node's own grid (rt_device.h: the node's box starts at RT_SPH_ORG and its longest
+// edge is RT_SPH_EDGE units), so that centre and radius are small integers and a 16-byte load
+// brings several spheres.  The grid's scale (units per length) is a float stored in the node record,
+// which the kernels use to bring the ray into the same grid.
+struct SphereD { double c[3], r; bool ok; };
+
+// the box's centre and half diagonal
+static SphereD voxel_sphere(const LeafTri &t)
 {
-    double c[3], r2 = 0;
-    for (int k = 0; k < 3; k++) { c[k] = (t.v0[k] + t.e1[k]) / 2; const double h = (t.e1[k] - t.v0[k]) / 2; r2 += h * h; }
-    const double r = std::sqrt(r2) * (1.0 + 1e-5) + 4e-7 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
-    LeafSphere s;
-    s.x = (float)c[0]; s.y = (float)c[1]; s.z = (float)c[2];
-    s.r = std::nextafter((float)r, INFINITY);
-    if (!std::isfinite(s.x) || !std::isfinite(s.y) || !std::isfinite(s.z) || !std::isfinite(s.r) || !(r == r)) {
-        s.x = s.y = s.z = 0.0f; s.r = INFINITY;
-    }
+    SphereD s; double r2 = 0;
+    for (int k = 0; k < 3; k++) { s.c[k] = (t.v0[k] + t.e1[k]) / 2; const double h = (t.e1[k] - t.v0[k]) / 2; r2 += h * h; }
+    s.r = std::sqrt(r2);
+    s.ok = std::isfinite(s.c[0]) && std::isfinite(s.c[1]) && std::isfinite(s.c[2]) && std::isfinite(s.r);
     return s;
 }
 
-// Bounding sphere of the triangle (v0, v0+e1, v0+e2) for the kernels' single-precision
-// pre-test: centre = centroid, radius = largest vertex distance, then inflated by 1e-5 of
-// itself plus 4e-7 of the centre's coordinate magnitudes (the rounding of the centre and of
-// the ray origin to float) and rounded up.  Anything not finite in float becomes an infinite
-// radius (the pre-test then always passes).
-static LeafSphere make_leaf_sphere(const LeafTri &t)
+// The smallest sphere around the triangle (v0, v0+e1, v0+e2): centred on the middle of the longest
+// edge when the opposite angle is right or obtuse, else on the circumcentre; if the circumcentre
+// comes out badly (a nearly degenerate triangle) or gives a larger sphere than the centroid, the
+// centroid is used.  Whatever the centre, the radius is the largest vertex distance from it, so
+// the sphere contains the triangle by construction.
+static SphereD triangle_sphere(const LeafTri &t)
 {
     double v[3][3], c[3];
     for (int k = 0; k < 3; k++) { v[0][k] = t.v0[k]; v[1][k] = t.v0[k] + t.e1[k]; v[2][k] = t.v0[k] + t.e2[k]; }
-    // the smallest sphere around the three vertices: centred on the middle of the longest edge when
-    // the opposite angle is right or obtuse, else on the circumcentre; if the circumcentre comes out
-    // badly (a nearly degenerate triangle) the centroid is used.  Whatever the centre, the radius is
-    // the largest vertex distance from it, so the sphere contains the triangle by construction.
     double len2[3];
     for (int i = 0; i < 3; i++) {
         const double *p = v[(i + 1) % 3], *q = v[(i + 2) % 3];
@@ -295,7 +293,6 @@ static LeafSphere make_leaf_sphere(const LeafTri &t)
         for (int k = 0; k < 3; k++) d2 += (v[i][k] - c[k]) * (v[i][k] - c[k]);
         if (!(d2 <= r2)) r2 = d2;
     }
-    // a circumcentre far outside a sliver would make the sphere larger than the centroid's: keep the smaller
     {
         double g[3], rg2 = 0;
         for (int k = 0; k < 3; k++) g[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
@@ -306,14 +303,77 @@ static LeafSphere make_leaf_sphere(const LeafTri &t)
         }
         if (rg2 < r2) { r2 = rg2; for (int k = 0; k < 3; k++) c[k] = g[k]; }
     }
-    const double r = std::sqrt(r2) * (1.0 + 1e-5) + 4e-7 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
-    LeafSphere s;
-    s.x = (float)c[0]; s.y = (float)c[1]; s.z = (float)c[2];
-    s.r = std::nextafter((float)r, INFINITY);
-    if (!std::isfinite(s.x) || !std::isfinite(s.y) || !std::isfinite(s.z) || !std::isfinite(s.r) || !(r == r)) {
-        s.x = s.y = s.z = 0.0f; s.r = INFINITY;
-    }
+    SphereD s;
+    for (int k = 0; k < 3; k++) s.c[k] = c[k];
+    s.r = std::sqrt(r2);
+    s.ok = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(s.r);
     return s;
+}
+
+// A sphere that holds the whole node in the node's grid (the box reaches at most RT_SPH_EDGE units
+// along every axis from RT_SPH_ORG, so its corners are within 0.9 RT_SPH_EDGE of RT_SPH_MID and the
+// largest radius is two edges): the pre-test passes
+// every ray that crosses the box.  The primitive tests only accept hits inside the node's window,
+// i.e. inside the box, so this is a valid stand-in for any record whose own sphere cannot be
+// expressed.
+static void store_sphere(uint32_t *dst, uint32_t x, uint32_t y, uint32_t z, uint32_t r)
+{
+#if RT_SPH_BITS == 8
+    dst[0] = x | (y << 8) | (z << 16) | (r << 24);
+#else
+    dst[0] = x | (y << 16);
+    dst[1] = z | (r << 16);
+#endif
+}
+static void store_whole_node_sphere(uint32_t *dst) { store_sphere(dst, RT_SPH_MID, RT_SPH_MID, RT_SPH_MID, RT_SPH_MAX); }
+
+// Units per length of a node's grid, as the float the kernels multiply with; 0 (pre-test off for
+// the node: every record gets the whole-node sphere) when the box is degenerate or so large or
+// small that single precision cannot hold the scale.  The lowest mantissa bit is cleared because
+// the node record keeps a flag there.
+static float node_grid_scale(const FlatNode &n)
+{
+    double ext = 0;
+    for (int k = 0; k < 3; k++) {
+        const double e = n.hi[k] - n.lo[k];
+        if (!std::isfinite(e) || !std::isfinite(n.lo[k])) return 0.0f;
+        if (e > ext) ext = e;
+    }
+    if (!(ext > 0)) return 0.0f;
+    const double sc = (double)RT_SPH_EDGE / ext;
+    if (!(sc > 1e-30 && sc < 1e30)) return 0.0f;
+    float f = (float)sc;
+    uint32_t bits;
+    std::memcpy(&bits, &f, 4);
+    bits &= ~1u;                                      // rounds the scale down by at most one ulp: the box still fits
+    if ((double)f > sc) bits -= 2u;                   // never above RT_SPH_EDGE / ext
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// The record's sphere in the node's grid, rounded outwards: the centre goes to the nearest grid
+// point and the radius grows by the distance it moved, by 1e-5 of itself (the primitive tests
+// accept rays that graze the primitive within rounding) and by 1/127 000 of the node's edge (the
+// kernels' own rounding when they bring the ray into the grid), then up to the next integer.
+static void pack_sphere(uint32_t *dst, const SphereD &s, const FlatNode &n, float scale)
+{
+    store_whole_node_sphere(dst);
+    if (!s.ok || !(scale > 0.0f)) return;
+    const double sc = (double)scale;
+    double disp2 = 0;
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        const double g = (s.c[k] - n.lo[k]) * sc + (double)RT_SPH_ORG;
+        if (!std::isfinite(g)) return;
+        double r = std::floor(g + 0.5);
+        if (r < 0) r = 0;
+        if (r > (double)RT_SPH_MAX) r = (double)RT_SPH_MAX;
+        q[k] = (uint32_t)r;
+        disp2 += (g - r) * (g - r);
+    }
+    const double rg = s.r * sc * (1.0 + 1e-5) + std::sqrt(disp2) * (1.0 + 1e-9) + 1e-3 * (RT_SPH_EDGE / 127u);
+    if (!(rg <= (double)RT_SPH_MAX)) return;
+    store_sphere(dst, q[0], q[1], q[2], (uint32_t)std::ceil(rg));
 }
 
 int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
@@ -461,7 +521,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     }
     std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
     std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
-    // four spare records at the end: the kernels fetch spheres four at a time without clamping
     // geometric normals: Vec3::operator^ and normalize as the kernels' cross / norm evaluate them
     std::vector<double> tri_normals(tris.size() / 3);
     for (size_t i = 0; i < tris.size() / 9; i++) {
@@ -470,9 +529,17 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         const double inv = 1 / std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
         for (int k = 0; k < 3; k++) tri_normals[3 * i + k] = n[k] * inv;
     }
-    std::vector<LeafSphere> leaf_sph(leaf_tris.size() + 8, LeafSphere{0.0f, 0.0f, 0.0f, 0.0f});
-    for (size_t i = 0; i < leaf_tris.size(); i++)
-        leaf_sph[i] = (leaf_tris[i].id & LEAF_VOXEL) ? make_voxel_sphere(leaf_tris[i]) : make_leaf_sphere(leaf_tris[i]);
+    // spare spheres at the end: the kernels fetch a step's spheres (at most RT_SPH_SPARE) without clamping
+    std::vector<uint32_t> leaf_sph((leaf_tris.size() + RT_SPH_SPARE) * RT_SPH_WORDS);
+    for (size_t i = 0; i < leaf_tris.size() + RT_SPH_SPARE; i++) store_whole_node_sphere(&leaf_sph[i * RT_SPH_WORDS]);
+    for (FlatNode &n : nodes) {
+        const float scale = node_grid_scale(n);
+        uint32_t bits;
+        std::memcpy(&bits, &scale, 4);
+        n.pad = bits | (n.pad & 1u);                  // grid scale, voxel flag in the lowest bit
+        for (uint32_t i = n.obj_begin; i < n.obj_begin + n.obj_count; i++)
+            pack_sphere(&leaf_sph[(size_t)i * RT_SPH_WORDS], (leaf_tris[i].id & LEAF_VOXEL) ? voxel_sphere(leaf_tris[i]) : triangle_sphere(leaf_tris[i]), n, scale);
+    }
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
     void *p_pp = nullptr, *p_pg = nullptr;
     auto up = [&](auto &vec, void **dst) {
@@ -490,7 +557,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.lights = (const rt_light *)p_light;
     s->dev.nodes = (const FlatNode *)p_nodes;
     s->dev.leaf_tris = (const LeafTri *)p_idx;
-    s->dev.leaf_sph = (const LeafSphere *)p_sph;
+    s->dev.leaf_sph = (const uint32_t *)p_sph;
     s->dev.tri_normals = (const double *)p_tris;
     s->dev.perlin_p = (const int32_t *)p_pp;
     s->dev.perlin_g = (const double *)p_pg;

@@ -7,10 +7,22 @@
 
 namespace rt {
 
-// Single-precision sphere around one triangle record, inflated so that a single-precision
-// test of a ray against it can never reject a ray that the fp64 triangle test accepts (see
-// make_leaf_sphere).  16 bytes: one load per triangle instead of five.
-struct LeafSphere { float x, y, z, r; };
+// Bounding spheres of the records of a node's run, for the kernels' single-precision pre-test.
+// They live in the node's own grid, RT_SPH_BITS bits a coordinate: the node's box starts at
+// RT_SPH_ORG on every axis and its longest edge is RT_SPH_EDGE units, which leaves half an edge of
+// room on either side for the centres of primitives that reach into the node from outside.
+// Centre and radius are unsigned integers:
+//   8 bits:  one word,  x | y << 8 | z << 16 | r << 24          (four spheres to a 16-byte load)
+//   16 bits: two words, x | y << 16 , z | r << 16               (two spheres to a 16-byte load)
+#ifndef RT_SPH_BITS
+#define RT_SPH_BITS 8
+#endif
+#define RT_SPH_WORDS (RT_SPH_BITS / 8)
+#define RT_SPH_MAX ((1u << RT_SPH_BITS) - 1u)
+#define RT_SPH_EDGE (127u << (RT_SPH_BITS - 8))
+#define RT_SPH_ORG (64u << (RT_SPH_BITS - 8))
+#define RT_SPH_MID (128u << (RT_SPH_BITS - 8))
+#define RT_SPH_SPARE 16          // spare spheres after the last record
 
 // One Group child as the kernels see it.  The object phase of the closest-hit engine reads
 // this table at wave-uniform addresses (scalar loads); a record carries everything that phase
@@ -37,7 +49,7 @@ struct DevScene {
     const rt_light    *lights;
     const FlatNode    *nodes;      // all meshes' nodes, 64-byte records
     const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
-    const LeafSphere  *leaf_sph;   // one bounding sphere per leaf_tris record (same index)
+    const uint32_t    *leaf_sph;   // one packed bounding sphere per leaf_tris record (same index, RT_SPH_WORDS words each)
     const double      *tri_normals; // normalize(e1 ^ e2) (3 doubles) by global triangle index
     const int32_t     *perlin_p;   // Perlin permutation and unit vectors (perlin_n, 3 x perlin_n); null without Perlin materials
     const double      *perlin_g;

@@ -251,7 +251,7 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 #endif
 // records whose spheres one triangle step tests
 #ifndef RT_PRE
-#define RT_PRE 7
+#define RT_PRE 16
 #endif
 #ifndef RT_WT
 #define RT_WT 8
@@ -341,7 +341,7 @@ __device__ __forceinline__ TriReg tri_load_uniform(u_leaftri p)
 
 template <bool FAST, int BLOCK>
 __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode,
-                                          uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], double *run_bt1, Counters &c)
+                                          uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], double *run_bt1, float4 (*rayf)[BLOCK], Counters &c)
 {
     const int tid = threadIdx.x;
     const V3 e = T.e, d = T.d, r = T.r;
@@ -349,7 +349,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     const FlatNode *nd = S.nodes + T.cur;
     const double lo0 = nd->lo[0], lo1 = nd->lo[1], lo2 = nd->lo[2];
     const double hi0 = nd->hi[0], hi1 = nd->hi[1], hi2 = nd->hi[2];
-    const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count, nd_voxels = nd->pad;
+    const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count, nd_pad = nd->pad;
     // per-axis plane distances; the node's own slab test and all 8 child tests use them
     const double al0 = qdiv<FAST>(lo0 - e.x, d.x, r.x), al1 = qdiv<FAST>(lo1 - e.y, d.y, r.y), al2 = qdiv<FAST>(lo2 - e.z, d.z, r.z);
     const double ah0 = qdiv<FAST>(hi0 - e.x, d.x, r.x), ah1 = qdiv<FAST>(hi1 - e.y, d.y, r.y), ah2 = qdiv<FAST>(hi2 - e.z, d.z, r.z);
@@ -439,19 +439,29 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         T.k = obj_begin; T.kend = obj_begin + obj_count;
         T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
         T.leaf = child_base == 0;
-        if (nd_voxels) run_bt1[tid] = n1;                   // voxel records read it back
+        if (nd_pad & 1u) run_bt1[tid] = n1;                 // voxel records read it back
+        // the ray for the sphere pre-test: the point where it enters this node's box, in the node's grid
+        const float sc = __uint_as_float(nd_pad & ~1u);
+        const float gx = (float)((e.x + d.x * n0) - lo0) * sc + (float)RT_SPH_ORG, gy = (float)((e.y + d.y * n0) - lo1) * sc + (float)RT_SPH_ORG;
+        const float gz = (float)((e.z + d.z * n0) - lo2) * sc + (float)RT_SPH_ORG;
+        rayf[0][tid] = make_float4(gx, gy, gz, rayf[0][tid].w);
+        rayf[1][tid].w = 4e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz)) + 2e-4f * (float)(RT_SPH_EDGE / 127u);
     }
 }
 
-// Triangle runs are walked four records per step with a cheap pre-test: a single-precision
-// test of the ray against the record's bounding sphere (16 bytes, one load) decides whether the
-// 80-byte record is fetched and the fp64 test made at all.  The sphere is inflated at build time
-// and the test carries margins for every single-precision rounding (ray origin, direction, the
-// cancellation in c2 - b^2/dd), so it only ever rejects rays that pass the triangle at a clear
-// distance: the fp64 test, which accepts rays within ~1e-15 of the triangle, would reject them
-// too.  A NaN or an overflow anywhere makes the pre-test pass.  The fetch path of the vector
-// memory pipeline handles one lane's load per clock when lanes read unrelated addresses, and
-// that, not arithmetic, bounds triangle steps: 1 + (few) loads per triangle instead of 5.
+// Triangle runs are walked RT_PRE records per step with a cheap pre-test: a single-precision
+// test of the ray against the record's bounding sphere decides whether the 80-byte record is
+// fetched and the fp64 test made at all.  The spheres are small integers in the grid of the node
+// that owns the run (see RT_SPH_BITS: with 8 bits a sphere is one word and a 16-byte load brings
+// four), rounded outwards at build time, and the test carries margins for every single-precision
+// rounding (the ray's entry point and direction, the cancellation in c2 - b^2/dd), so it only ever
+// rejects rays that pass the primitive at a clear distance: the fp64 test, which accepts rays
+// within ~1e-15 of the triangle, would reject them too.  A NaN or an overflow anywhere makes the
+// pre-test pass.  A step's fixed cost (the candidate's fp64 test, bookkeeping, the vote on the
+// next step kind) is spread over RT_PRE records, and a record costs a quarter of a load plus five
+// for the few that pass, instead of five for every record.
+// RayF is the lane's ray for that test: ex..ez = the point where the ray enters the node's box,
+// in the node's grid (written when the run opens), dx..dz = the direction in single precision.
 struct RayF { float ex, ey, ez, dx, dy, dz, inv_dd, slack; };
 __device__ __forceinline__ RayF ray_single(V3 e, V3 d)
 {
@@ -459,33 +469,43 @@ __device__ __forceinline__ RayF ray_single(V3 e, V3 d)
     r.ex = (float)e.x; r.ey = (float)e.y; r.ez = (float)e.z;
     r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
     r.inv_dd = __builtin_amdgcn_rcpf(__builtin_fmaf(r.dx, r.dx, __builtin_fmaf(r.dy, r.dy, r.dz * r.dz)));   // 1 ulp, inside the margins
-    r.slack = 4e-7f * (fabsf(r.ex) + fabsf(r.ey) + fabsf(r.ez));
+    r.slack = 0.0f;
     return r;
 }
-__device__ __forceinline__ LeafSphere sph_load(const LeafSphere *p)
+struct SphQ { uint32_t w[RT_SPH_WORDS]; };
+__device__ __forceinline__ bool sph_pass(const SphQ &q, const RayF &r)
 {
-    const float4 v = *reinterpret_cast<const float4 *>(p);
-    LeafSphere s; s.x = v.x; s.y = v.y; s.z = v.z; s.r = v.w;
-    return s;
-}
-__device__ __forceinline__ bool sph_pass(const LeafSphere &s, const RayF &r)
-{
-    const float ox = s.x - r.ex, oy = s.y - r.ey, oz = s.z - r.ez;
+#if RT_SPH_BITS == 8
+    const float sx = (float)(q.w[0] & 255u), sy = (float)((q.w[0] >> 8) & 255u), sz = (float)((q.w[0] >> 16) & 255u), sr = (float)(q.w[0] >> 24);
+#else
+    const float sx = (float)(q.w[0] & 0xFFFFu), sy = (float)(q.w[0] >> 16), sz = (float)(q.w[1] & 0xFFFFu), sr = (float)(q.w[1] >> 16);
+#endif
+    const float ox = sx - r.ex, oy = sy - r.ey, oz = sz - r.ez;
     const float b = __builtin_fmaf(ox, r.dx, __builtin_fmaf(oy, r.dy, oz * r.dz));
     const float c2 = __builtin_fmaf(ox, ox, __builtin_fmaf(oy, oy, oz * oz));
     const float perp2 = __builtin_fmaf(-(b * r.inv_dd), b, c2);          // squared distance of the centre from the ray's line
-    const float R = s.r + r.slack;
+    const float R = sr + r.slack;
     const float bound = __builtin_fmaf(R, R, 4e-6f * c2);
     return !(perp2 > bound);
 }
-// A lane that has just opened a triangle run loads the spheres of its first four records (a
-// run shorter than four reads into the records that follow it, which are masked out when tested;
-// the array ends with four spare records).
-__device__ __forceinline__ void run_open(const DevScene &S, TravState &T, LeafSphere (&Q)[RT_PRE])
+// The spheres of records k .. k+RT_PRE-1 (a run shorter than that reads into the records that
+// follow it, which are masked out when tested; the array ends with RT_PRE spare spheres).
+__device__ __forceinline__ void sph_fetch(const DevScene &S, uint32_t k, SphQ (&Q)[RT_PRE])
 {
-    const LeafSphere *P = S.leaf_sph + T.k;
+    static_assert((RT_PRE * RT_SPH_WORDS) % 4 == 0 && RT_PRE <= RT_SPH_SPARE && RT_PRE <= 16, "spheres are fetched 16 bytes to a load");
+    const uint32_t *P = S.leaf_sph + (size_t)k * RT_SPH_WORDS;
+    uint32_t *out = &Q[0].w[0];
 #pragma unroll
-    for (uint32_t i = 0; i < RT_PRE; i++) Q[i] = sph_load(P + i);
+    for (uint32_t i = 0; i < RT_PRE * RT_SPH_WORDS; i += 4) {
+        uint4 v;
+        __builtin_memcpy(&v, P + i, 16);                 // aligned to the sphere's size only
+        out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+    }
+}
+// A lane that has just opened a run loads the spheres of its first records.
+__device__ __forceinline__ void run_open(const DevScene &S, TravState &T, SphQ (&Q)[RT_PRE])
+{
+    sph_fetch(S, T.k, Q);
     T.pend = 0; T.cand = RT_MISS;
 }
 // A voxel of an implicit surface (record with LEAF_VOXEL in its id: v0 / e1 = lower / upper
@@ -533,7 +553,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #define RT_RAYF_PUT() { const RayF q_ = ray_single(T.e, T.d); rayf[0][tid] = make_float4(q_.ex, q_.ey, q_.ez, q_.inv_dd); rayf[1][tid] = make_float4(q_.dx, q_.dy, q_.dz, q_.slack); }
     TravState T = {};
     TriReg R = {};
-    LeafSphere Q[RT_PRE] = {};
+    SphQ Q[RT_PRE] = {};
     int mode = TM_FETCH;
     // rays are handed to a wave in batches of 64 .. batch_max: a quarter of an even share of what is left
     const uint32_t nwaves = gridDim.x * (BLOCK / 64);
@@ -738,8 +758,8 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #endif
                 if (mode == TM_POP) pop_now();
                 const bool in = mode == TM_NODE;
-                if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, c); }
-                else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, c); }
+                if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
+                else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
                 if (in && mode == TM_TRI) run_open(S, T, Q);
                 RT_TICK(inner)
                 continue;
@@ -780,11 +800,8 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4
                         c.prim += take;
 #endif
-                        // the spheres of the four records after these (past the run's end they belong to
-                        // other runs, or are the array's spare records, and are masked out when tested)
-                        const LeafSphere *P = S.leaf_sph + T.k;
-#pragma unroll
-                        for (uint32_t i = 0; i < RT_PRE; i++) Q[i] = sph_load(P + i);
+                        // the spheres of the records after these
+                        sph_fetch(S, T.k, Q);
                     }
                     // 3. request the first waiting record (candidates are tested in list order, so
                     //    "the last equal hit wins", octree.cpp:31, is kept)
