@@ -566,6 +566,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.nlights = (int32_t)d->nlights;
     s->dev.regular = 1;
     s->dev.nbig = 0;
+    {
+        // what one sweep over the objects costs, in box-test units: one per object, two per triangle
+        // of a mesh that is tested inside the sweep.  Timed on scenes with 3 (best weight >= 24) and
+        // 25 units (best weight 8-10).
+        uint64_t units = 0;
+        for (const DevObject &q : objs) units += 1 + 2 * (uint64_t)q.ntri;
+        s->dev.obj_weight = units <= 4 ? 24 : (units >= 20 ? 8 : (int32_t)(28 - units));
+    }
     for (const DevObject &q : objs)
         if ((q.type == RT_OBJ_MESH && q.ntri == 0) || q.type == RT_OBJ_HEART || q.type == RT_OBJ_GENUS2) {
             // an octree with inner nodes; past RT_MAX_BIG of them the last box grows to hold the rest

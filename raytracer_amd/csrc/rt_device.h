@@ -58,7 +58,7 @@ struct DevScene {
     int32_t regular;               // every node coordinate is 0 or of magnitude 1e-100 .. 1e100
     int32_t nbig;                  // octrees with inner nodes whose root boxes are listed below (at most RT_MAX_BIG)
     int32_t perlin_n;
-    int32_t pad;
+    int32_t obj_weight;            // weight of a lane that waits for an object phase when a wave chooses its next step kind (8 = a triangle-step lane)
     double  background[3];
     float   big_lo[4][3], big_hi[4][3];
 };

@@ -261,12 +261,17 @@ enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 
 #define RT_OI_LOCAL 0x40000000
 // Which kind of step a wave runs next: the one with the largest weighted count of waiting
 // lanes.  Weights are in eighths of a triangle-step lane (triangle steps weigh 8); found by
-// timing, a node step is preferred at 2/3 of the triangle lanes, an object phase needs 4/3.
+// timing, a node step is preferred at 4/5 of the triangle lanes.  The weight of an object phase
+// depends on what a sweep over the scene's objects costs and comes with the scene
+// (DevScene::obj_weight): an object phase is also where lanes that have finished get their next
+// ray, so the cheaper the sweep, the sooner it pays to go back to it.
 #ifndef RT_WN
-#define RT_WN 12
+#define RT_WN 10
 #endif
-#ifndef RT_WO
-#define RT_WO 6
+#ifdef RT_WO
+#define RT_OBJ_WEIGHT(S) (RT_WO)
+#else
+#define RT_OBJ_WEIGHT(S) ((S).obj_weight)
 #endif
 template <bool FAST> __device__ __forceinline__ double tmin2(double a, double b) { return FAST ? fmin(a, b) : smin(a, b); }
 template <bool FAST> __device__ __forceinline__ double tmax2(double a, double b) { return FAST ? fmax(a, b) : smax(a, b); }
@@ -747,7 +752,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
             const unsigned long long mN = __ballot(mode == TM_NODE || mode == TM_POP);
             const unsigned long long mT = __ballot(mode == TM_TRI);
             if ((mO | mN | mT) == 0ull) { finished = true; break; }
-            const int nO = __popcll(mO) * RT_WO, nN = __popcll(mN) * RT_WN, nT = __popcll(mT) * RT_WT;
+            const int nO = __popcll(mO) * RT_OBJ_WEIGHT(S), nN = __popcll(mN) * RT_WN, nT = __popcll(mT) * RT_WT;
             if (nO != 0 && nO >= nN && nO >= nT) break;
             if (nN != 0 && nN >= nT) {
                 // -------------------------------------------------------- node step
@@ -819,7 +824,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 const int nT = __popcll(__ballot(mode == TM_TRI)) * RT_WT;
                 if (nT == 0) break;
                 if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) * RT_WN >= nT) break;
-                if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) * RT_WO >= nT) break;
+                if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) * RT_OBJ_WEIGHT(S) >= nT) break;
             }
             RT_TICK(leaf)
         }
