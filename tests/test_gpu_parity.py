@@ -116,6 +116,48 @@ def test_trace_rays_bit_exact_vs_oracle(seed, ntri, max_size, edge):
         assert np.array_equal(c1, c2)         # rays, inner visits, leaf visits, primitive tests
 
 
+@pytest.mark.parametrize("case", ["far", "slivers", "flat", "mixed_sizes"])
+def test_sphere_pretest_never_rejects_a_hit(case):
+    """The single-precision sphere pre-test works in a per-node integer grid; geometry that is hard
+    on it must still give the oracle's ids, distances and test counts bit for bit: a mesh far from
+    the origin (coordinates 1e8 times the triangle size), needle triangles, a mesh with no extent
+    along one axis, and triangles from 1e-4 to 1 of the mesh's size in one octree."""
+    rng = np.random.default_rng(91)
+    if case == "far":
+        tris = scenes.soup(8000, seed=91, edge_lo=1e-3, edge_hi=1e-2)
+        off = np.array([1.0e5, -2.0e5, 3.0e5])
+        tris = tris + np.tile(off, 3)
+        lo, hi = off - 0.5, off + 1.5
+    elif case == "slivers":
+        tris = scenes.soup(6000, seed=92, edge_lo=1e-2, edge_hi=2e-1)
+        tris[:, 6:9] = tris[:, 0:3] + (tris[:, 3:6] - tris[:, 0:3]) * 0.5 + rng.normal(0, 1e-7, (len(tris), 3))   # third vertex on the first edge
+        lo, hi = np.full(3, -0.5), np.full(3, 1.5)
+    elif case == "flat":
+        tris = scenes.soup(5000, seed=93, edge_lo=5e-3, edge_hi=5e-2)
+        tris[:, 1::3] = 0.25                                   # every vertex at y = 0.25
+        lo, hi = np.full(3, -0.5), np.full(3, 1.5)
+    else:
+        tris = np.concatenate([scenes.soup(5000, seed=94, edge_lo=1e-4, edge_hi=1e-3), scenes.soup(300, seed=95, edge_lo=0.3, edge_hi=1.0)])
+        lo, hi = np.full(3, -0.5), np.full(3, 1.5)
+    desc = _mesh_desc(np.ascontiguousarray(tris), octree_max_size=16, octree_max_depth=15)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    assert so.octree_stats(0) == sg.octree_stats(0)
+    n = 30000
+    rays = np.zeros(n, RAY_DT)
+    rays["e"] = rng.uniform(lo, hi, (n, 3))
+    # aim at points of the mesh so that most rays hit something, many of them at grazing distance
+    v = tris.reshape(-1, 3, 3)
+    pick = rng.integers(0, len(v), n)
+    w = rng.dirichlet((1, 1, 1), n)
+    target = (v[pick] * w[:, :, None]).sum(axis=1)
+    d = target - rays["e"]
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    p1, d1, n1, c1 = so.trace_rays(rays, 0.0, 1e10)
+    p2, d2, n2, c2 = sg.trace_rays(rays, 0.0, 1e10)
+    assert (p1 != MISS).mean() > 0.5
+    assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
+
+
 def test_primary_id_buffer_bit_exact_small():
     desc, cam = scenes.soup_scene(50000, seed=9)
     so, sg = orc.OracleScene(desc), hip.HipScene(desc)
