@@ -1,3 +1,6 @@
+"""Share of pre-tested records that reach the fp64 primitive test, on the bunny and atrium scenes.
+Needs a library built with -DRT_STEP_STATS=5 (tools/build_variant.sh st5 -DRT_STEP_STATS=5, then
+RT_HIP_LIB=raytracer_amd/_var/st5.so): counter 0 then counts those records, counter 3 the pre-tests."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
