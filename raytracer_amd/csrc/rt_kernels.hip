@@ -552,8 +552,9 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
     __shared__ double run_bt1[BLOCK];        // upper end of the window of the lane's current primitive run
-    // the lane's ray in single precision (see RayF): formed once whenever T.e / T.d change and read
-    // back by every triangle step, which is cheaper than converting it again each step
+    // the lane's ray for the sphere pre-test (see RayF), read back by every triangle step: direction
+    // and 1/|d|^2 are formed whenever T.d changes, the entry point and its slack when a run opens
+    // (node_step)
     __shared__ float4 rayf[2][BLOCK];
 #define RT_RAYF_PUT() { const RayF q_ = ray_single(T.e, T.d); rayf[0][tid] = make_float4(q_.ex, q_.ey, q_.ez, q_.inv_dd); rayf[1][tid] = make_float4(q_.dx, q_.dy, q_.dz, q_.slack); }
     TravState T = {};
