@@ -607,10 +607,12 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     }
     s->materials = mats;
     s->nlights = (int)d->nlights;
-    s->dev.diffuse_only = 1;                          // over the materials that objects use
+    s->dev.shade_kinds = 0;                           // over the materials that objects use
     for (const DevObject &q : objs) {
         const rt_material &m = mats[q.material];
-        if (m.type != (RT_MAT_NORMAL | RT_MAT_MONTECARLO) || m.perlin != RT_PERLIN_NONE || m.check != RT_CHECK_NONE) s->dev.diffuse_only = 0;
+        if (!(m.type & RT_MAT_MONTECARLO) || m.perlin != RT_PERLIN_NONE || m.check != RT_CHECK_NONE) s->dev.shade_kinds |= 7;
+        if (m.type & RT_MAT_SPECULAR) s->dev.shade_kinds |= 1;
+        if (m.type & RT_MAT_TRANSPARENT) s->dev.shade_kinds |= 2;
     }
     for (const rt_material &m : mats) {
         int push = ((m.type & RT_MAT_NORMAL) ? 1 + s->nlights : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 2 : 0);

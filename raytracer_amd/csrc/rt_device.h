@@ -61,7 +61,7 @@ struct DevScene {
     int32_t obj_weight;            // weight of a lane that waits for an object phase when a wave chooses its next step kind (8 = a triangle-step lane)
     double  background[3];
     float   big_lo[4][3], big_hi[4][3];
-    int32_t diffuse_only;          // every material is plain Monte-Carlo diffuse (NORMAL | MONTECARLO): k_shade's short form serves
+    int32_t shade_kinds;           // material features the objects use: 1 mirror lobe, 2 dielectric lobe, 4 Phong / Perlin / check (any of these: 7)
     int32_t pad;
 };
 

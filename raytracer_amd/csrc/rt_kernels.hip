@@ -1298,10 +1298,12 @@ __device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
 #ifdef RT_SHADE_WAVES
 __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
 #endif
-// ALL = false is the kernel for scenes whose materials are all Monte-Carlo diffuse (type
-// NORMAL | MONTECARLO, no Perlin or check variants): the mirror and dielectric lobes and the Phong /
-// Whitted branch are compiled out, which is all that differs.
-template <bool ALL>
+// KINDS says which material features the scene's objects use (DevScene::shade_kinds): 1 = a mirror
+// lobe, 2 = a dielectric lobe, 4 = the Phong / Whitted branch (materials without MONTECARLO, Perlin
+// and check variants).  What a scene does not use is compiled out, which is all that differs: the
+// kernel for plain Monte-Carlo diffuse scenes needs 163 registers a lane instead of 256 and runs
+// three waves per SIMD instead of two.
+template <int KINDS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayStack src, uint64_t base, uint32_t count, RayDest D)
 {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1347,7 +1349,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     // mc: the Monte-Carlo branch (scene.cpp:205-304); otherwise the Phong / Whitted branch
     // (scene.cpp:305-375): no roulette, no emission, ambient + shadowed diffuse / specular terms
     // per light instead of the diffuse bounce, the mirror colour instead of getColor()
-    const bool mc = ALL ? (mtype & RT_MAT_MONTECARLO) != 0 : true;
+    const bool mc = (KINDS & 4) ? (mtype & RT_MAT_MONTECARLO) != 0 : true;
     V3 cc = mcolor;
     bool alive = shade;
     if (shade && mc && jt > A.rus_jump) {                                    // Russian roulette, scene.cpp:208-212
@@ -1358,7 +1360,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
 
     // ---- diffuse lobe, scene.cpp:213-248
     const bool lobeN = alive && mc && (mtype & RT_MAT_NORMAL);
-    const bool phongN = ALL && alive && !mc && (mtype & RT_MAT_NORMAL);
+    const bool phongN = (KINDS & 4) && alive && !mc && (mtype & RT_MAT_NORMAL);
     V3 w = normal, dn = mk(0, 0, 0), wn = normal;
     if (lobeN) {
         double r1 = RT_PI * 2 * draw(key, SLOT_DIFF1);
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     }
 
     // ---- mirror lobe, scene.cpp:249-266
-    const bool lobeS = ALL && alive && (mtype & RT_MAT_SPECULAR);
+    const bool lobeS = (KINDS & 1) && alive && (mtype & RT_MAT_SPECULAR);
     V3 md = mk(0, 0, 0);
     if (lobeS) {
         md = rd - (normal * dot(normal, rd)) * 2;
@@ -1469,7 +1471,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     const V3 mweight = mc ? mcolor : ld3(mat.mirror);                        // scene.cpp:265 / :341
 
     // ---- dielectric lobe, scene.cpp:267-303 (and :343-373)
-    const bool lobeT = ALL && alive && (mtype & RT_MAT_TRANSPARENT);
+    const bool lobeT = (KINDS & 2) && alive && (mtype & RT_MAT_TRANSPARENT);
     V3 kk = mk(1, 1, 1), r = mk(0, 0, 0), rfr = mk(0, 0, 0);
     double R = 0;
     bool tir = false;
@@ -1605,8 +1607,14 @@ hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &sr
                         const RayDest &dst, hipStream_t st)
 {
     if (!count) return hipSuccess;
-    if (S.diffuse_only) hipLaunchKernelGGL(k_shade<false>, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, src, base, count, dst);
-    else hipLaunchKernelGGL(k_shade<true>, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, src, base, count, dst);
+    const dim3 grid((count + RT_BLOCK - 1) / RT_BLOCK), block(RT_BLOCK);
+    switch (S.shade_kinds) {
+    case 0: hipLaunchKernelGGL(k_shade<0>, grid, block, 0, st, S, A, src, base, count, dst); break;
+    case 1: hipLaunchKernelGGL(k_shade<1>, grid, block, 0, st, S, A, src, base, count, dst); break;
+    case 2: hipLaunchKernelGGL(k_shade<2>, grid, block, 0, st, S, A, src, base, count, dst); break;
+    case 3: hipLaunchKernelGGL(k_shade<3>, grid, block, 0, st, S, A, src, base, count, dst); break;
+    default: hipLaunchKernelGGL(k_shade<7>, grid, block, 0, st, S, A, src, base, count, dst); break;
+    }
     return hipGetLastError();
 }
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, int tone, uint8_t *bgr, hipStream_t st)
