@@ -1295,15 +1295,15 @@ __device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
 }
 
 // Consume the hits of chunk [base, base+count) of `src`; follow-up rays are appended to D.
-#ifdef RT_SHADE_WAVES
-__attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
-#endif
 // KINDS says which material features the scene's objects use (DevScene::shade_kinds): 1 = a mirror
 // lobe, 2 = a dielectric lobe, 4 = the Phong / Whitted branch (materials without MONTECARLO, Perlin
 // and check variants).  What a scene does not use is compiled out, which is all that differs: the
 // kernel for plain Monte-Carlo diffuse scenes needs 163 registers a lane instead of 256 and runs
 // three waves per SIMD instead of two.
 template <int KINDS>
+#ifdef RT_SHADE_WAVES
+__attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+#endif
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayStack src, uint64_t base, uint32_t count, RayDest D)
 {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
