@@ -20,6 +20,8 @@ def per_kernel(path):
     n = collections.Counter()
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]                     # template instances are printed with their return type
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
     return agg, n
