@@ -8,8 +8,10 @@ every pixel into a full-frame fp64 radiance buffer (device resident), the buffer
 onto rank 0 (RCCL) and rank 0 resolves the frame to bytes.  At N = 1 the workload is the
 single-GPU benchmark configuration (bunny-class ~69 k triangle mesh in a triangle Cornell box,
 octree leaf capacity 128 as in the reference, 1024 x 1024, 256 spp).  For N > 1 the per-GPU
-work is kept fixed (weak scaling): the frame has 256*N samples per pixel, rank g renders
-sample indices [256 g, 256 (g+1)).
+work is kept fixed by default (weak scaling): the frame has 256*N samples per pixel, rank g
+renders sample indices [256 g, 256 (g+1)).  `--scaling strong` keeps the frame fixed instead
+(bunny: 256 spp, atrium: 1024 spp = the target configuration) and deals its samples to the ranks,
+so that the times of an N = 1 and an N = 8 run give the efficiency T1 / (N TN) directly.
 
 The timed region starts with the scene already uploaded (octree build + upload are one-time
 costs outside it) and contains render + reduce + resolve.  `value` = all rays traced by all
@@ -34,15 +36,17 @@ from raytracer_amd.desc import render_params  # noqa: E402
 from raytracer_amd.parallel import dist_env, sample_slice  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (lane-ops/s, FMA = 1)
+VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (operations/s, a fused multiply-add = 1:
+                               # the path is built without contraction, so an operation is one flop)
+RAY_RECORD_BYTES = 96.0        # a pending ray: 12 eight-byte fields
+SHADE_READ_BYTES = 40.0        # what shading reads of every ray: meta word, hit id, throughput
 
 
-def algorithmic_bytes(cnt, tri_bytes):
-    """Bytes the closest-hit kernel has to touch for the work it did: one 64-byte node record
-    per node visit (child boxes are derived, not fetched), one triangle record + its 4-byte
-    index per primitive test, 48 bytes of ray in and 16 bytes of hit out per ray."""
-    rays, inner, leaf, prim = (float(x) for x in cnt)
-    return 64.0 * (inner + leaf) + (tri_bytes + 4.0) * prim + (48.0 + 16.0) * rays
+def shade_bytes(flow):
+    """Bytes the shading kernel has to move for the rays it handled (a lower bound: the 64 bytes
+    more that a shaded hit reads and the 24 bytes a contributing ray adds to its pixel are left
+    out): the fields every ray is read for, and one record written per follow-up ray."""
+    return SHADE_READ_BYTES * flow["shaded_in"] + RAY_RECORD_BYTES * (flow["appended_class0"] + flow["appended_class1"])
 
 
 def algorithmic_lane_ops(cnt):
@@ -56,7 +60,8 @@ def cpu_baseline(desc, cam, W, H, n, m, seed, budget_s=20.0):
     """The CPU oracle (a port of the reference path) on this box's host cores, on a bounded
     sample of the same workload: whole image rows spread over the frame, all samples."""
     from oracle import orc
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # every host core this process may use (the GPU box sets OMP_NUM_THREADS to its share of the machine)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
     so = orc.OracleScene(desc)
     c = orc.camera_init(**cam)
     prm = render_params(W, H, n, m, seed=seed)
@@ -86,6 +91,9 @@ def main():
     ap.add_argument("--workload", choices=["bunny", "atrium"], default="bunny",
                     help="bunny: the single-GPU benchmark configuration (default); atrium: the Sponza-class scene "
                          "(~262 k triangles, rectangular light) at 1920 x 1080, 128 spp per GPU unless --spp-root is given")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: samples per GPU fixed (default); strong: the frame fixed (bunny 256 spp, atrium 1024 spp), "
+                         "its samples dealt to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -112,15 +120,17 @@ def main():
         W, H = (1920, 1080) if a.size == 1024 else (a.size * 16 // 9, a.size)
         n = a.spp_root
         m = (8 if a.spp_root == 16 else a.spp_root) * world      # 128 spp per GPU: 1024 spp on 8 GPUs
+        if a.scaling == "strong":
+            n, m = (32, 32) if a.spp_root == 16 else (a.spp_root, a.spp_root)   # the target frame: 1024 spp whatever N is
         desc, cam = scenes.atrium_scene()
         label = "Sponza-class atrium"
     else:
         W = H = a.size
         n = a.spp_root
-        m = a.spp_root * world                  # weak scaling: 256 samples per pixel per GPU
+        m = a.spp_root * (world if a.scaling == "weak" else 1)   # weak scaling: 256 samples per pixel per GPU
         desc, cam = scenes.bunny_cornell_scene()    # 69 564-triangle mesh, Cornell box of triangle meshes, sphere light
         label = "bunny-class mesh"
-    per_gpu = n * m // world
+    per_gpu = -(-n * m // world)
     ntris = sum(len(x) for x in desc.meshes)
     t0 = time.time()
     sc = hip.HipScene(desc)
@@ -157,6 +167,7 @@ def main():
     cnt.zero_()
     sc.set_profiling(True)
     sc.get_profile(reset=True)
+    sc.get_ray_flow(reset=True)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -165,6 +176,7 @@ def main():
     dt = time.perf_counter() - t0
     sc.check()
     prof = sc.get_profile()
+    flow = sc.get_ray_flow()
     sc.set_profiling(False)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -180,21 +192,30 @@ def main():
         steps = max(a.steps, 1)
         rays_per_step = total[0] / steps
         paths_per_step = float(W) * H * n * m
-        # dominant kernel: the closest-hit kernel, timed with HIP events around every launch
-        tri_bytes = 72.0
+        # Dominant kernel: the closest-hit kernel, timed with HIP events around every launch on the
+        # stream it runs on.  Its scene data stays in the caches, so what binds it is fp64 vector
+        # arithmetic, not HBM: the headline roofline prices the work it did (slab tests and
+        # primitive tests by the device's own counters) against the fp64 vector peak.  HBM traffic
+        # comes from counter passes of the same command (profiles/, replayed here: a --pmc pass
+        # cannot run inside this process) and is reported as a secondary entry.
         launches = max(prof["trace_launches"], 1.0)
         avg_ms = prof["trace_ms"] / launches
-        bytes_per_launch = algorithmic_bytes(mine, tri_bytes) / launches
         ops_per_launch = algorithmic_lane_ops(mine) / launches
-        achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         achieved_ops = ops_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile) and a.workload == "bunny":      # the counters were collected on the default workload
+        pmc = {}
+        pfile = os.path.join(ROOT, "profiles", "pmc_" + a.workload + ".json")
+        if os.path.exists(pfile):
             try:
-                traffic = json.load(open(tfile)).get("bytes_per_trace_launch")
+                pmc = json.load(open(pfile))
             except Exception:
-                traffic = None
+                pmc = {}
+        ptrace, pshade = pmc.get("trace", {}), pmc.get("shade", {})
+        traffic = ptrace.get("hbm_bytes_per_launch")
+        src = f"replayed from profiles/pmc_{a.workload}.json (rocprofv3 --pmc passes of this command, {pmc.get('collected', 'n/a')})" if pmc else None
+        shade_launches = max(prof["shade_launches"], 1.0)
+        shade_avg_ms = prof["shade_ms"] / shade_launches
+        shade_b = shade_bytes(flow) / shade_launches
+        shade_gbs = shade_b / (shade_avg_ms * 1e-3) / 1e9 if shade_avg_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s (whole job; spp/s and roofline fractions alongside)",
             "value": rays_per_step * steps / dt / 1e6,
@@ -202,7 +223,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -215,17 +236,29 @@ def main():
             "mpaths_per_s": paths_per_step * steps / dt / 1e6,
             "rays_per_path": rays_per_step / paths_per_step,
             "upload_s": upload_s,
-            "roofline": {"kernel": "rt::k_trace (octree closest hit)", "bound": "hbm",
-                         "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "roofline": {"kernel": "rt::k_trace (octree closest hit)", "bound": "valu-fp64",
+                         "achieved": achieved_ops / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved_ops / VALU_FP64_PEAK, "traffic": traffic, "traffic_source": src,
+                         "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_ops_per_launch": ops_per_launch,
+                         "ops_model": "26 per slab test (9 at an inner node, 1 at a leaf) + 50 per primitive test, counted on the device",
+                         "valu_issue_share": ptrace.get("valu_issue_share"), "active_lanes_per_valu_inst": ptrace.get("active_lanes_per_valu_inst"),
                          "share_of_step_time": prof["trace_ms"] * 1e-3 / dt},
-            "roofline_valu": {"kernel": "rt::k_trace (octree closest hit)", "bound": "valu-fp64",
-                              "achieved": achieved_ops / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "Tlane-op/s",
-                              "frac": achieved_ops / VALU_FP64_PEAK},
+            "roofline_shade": {"kernel": "rt::k_shade (shading + ray append)", "bound": "hbm",
+                               "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
+                               "traffic": pshade.get("hbm_bytes_per_launch"), "traffic_source": src if pshade else None,
+                               "launches": shade_launches, "avg_launch_ms": shade_avg_ms, "algorithmic_bytes_per_launch": shade_b,
+                               "share_of_step_time": prof["shade_ms"] * 1e-3 / dt},
             "stage_ms_per_step": {"trace": prof["trace_ms"] / steps, "shade": prof["shade_ms"] / steps,
                                   "rounds": prof["rounds"] / steps},
         }
+        if traffic and avg_ms > 0:
+            gbs = traffic / (avg_ms * 1e-3) / 1e9
+            out["roofline_hbm"] = {"kernel": "rt::k_trace (octree closest hit)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                                   "note": "measured traffic of the profiled run over this run's launch time: the scene is cache resident, HBM does not bind"}
+        for key in ("roofline", "roofline_shade", "roofline_hbm"):
+            if key in out and not (0.0 <= out[key]["frac"] <= 1.0):
+                raise SystemExit(f"bench.py: {key}.frac = {out[key]['frac']:.3f} is not a fraction of a peak -- the model behind it is wrong")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(desc, cam, W, H, n, m, seed, a.cpu_budget)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

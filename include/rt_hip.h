@@ -245,6 +245,11 @@ int rt_scene_check(rt_scene *scene, void *stream);
  * the totals after reading. */
 int rt_scene_set_profiling(rt_scene *scene, int enable);
 int rt_scene_get_profile(rt_scene *scene, double out[6], int reset);
+/* Rays that went through the path-tracing pipeline since the last reset, counted by the host
+ * driver (always, profiling enabled or not): out = {first rays generated, rays traced and handed
+ * to shading, follow-up rays appended that end inside object phases, follow-up rays appended that
+ * reach an octree with inner nodes}.  No counterpart in the reference. */
+int rt_scene_get_ray_flow(rt_scene *scene, double out[4], int reset);
 
 /* colorArray_ -> bytes: average, Vec4::regularize (types.h:167-177), int(c*255) stored B,G,R
  * (scene.cpp:183-185).  bgr = height x width x 3 bytes, bottom row first. */
@@ -259,7 +264,9 @@ int rt_resolve_tone_bgr8(const double *radiance_sum, int width, int height, int 
 int rt_resolve_tone_bgr8_host(const double *radiance_sum, int width, int height, int spp, int tone, uint8_t *bgr);
 
 /* Snapshot (bmpgenerator.cpp:3-45) with fixed-width header fields: 14 + 40 byte headers,
- * 24 bpp, bottom-up rows, no row padding (as the reference writes it). */
+ * 24 bpp, bottom-up rows.  Rows are padded to a multiple of four bytes as the format requires; the
+ * reference writes no padding, which is the same bytes whenever 3 * width is a multiple of four
+ * (every size its driver uses, main.cpp:13-23) and an unreadable file otherwise. */
 int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename);
 
 /* Video file for the animation loop -- AviSaver::Open / AddImg / Save (AviSaver.cpp:9-75, used by

@@ -10,8 +10,8 @@
 //     ImplicitSurface play in the reference, Surface.h:131-174).
 //   * the sampler constants that are private members without setters in the reference
 //     (scene.h:52-54) are settable: setSampleNum, setMaxJump, setRusJump, setSeed, setFaceForward.
-//   * only Monte-Carlo materials are accepted (the legacy Phong branch, scene.cpp:305-375, is
-//     not on this path): setRootNode / run report -1 for others.
+//   * both shading branches of Scene::rayColor are on the device: materials with MONTECARLO
+//     (scene.cpp:205-304) and the Phong / Whitted ones without it (scene.cpp:305-375).
 // Header-only; link with librt_hip.so.
 #pragma once
 #include <cmath>

@@ -62,6 +62,7 @@ struct rt_scene {
     int profiling = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     double prof[6] = {0, 0, 0, 0, 0, 0}; // trace launches, trace ms, shade launches, shade ms, generate launches, rounds
+    double flow[4] = {0, 0, 0, 0};       // first rays generated, rays traced and shaded, follow-up rays appended (class 0, class 1)
 };
 
 extern "C" {
@@ -688,16 +689,39 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
     return (end && *end == 0 && x > 0) ? (uint64_t)x : dflt;
 }
 
-static int ensure_stacks(rt_scene *s, uint64_t cap, hipStream_t st)
+static void free_stacks(rt_scene *s)
 {
-    if (s->stack[0][0].cap >= cap) return 0;
-    HIP_TRY(hipStreamSynchronize(st));
     for (int c = 0; c < 2; c++)
         for (int k = 0; k < 2; k++) {
-            if (s->stack_mem[c][k]) { HIP_TRY(hipFree(s->stack_mem[c][k])); s->stack_mem[c][k] = nullptr; s->stack[c][k].cap = 0; }
-            const size_t words = (size_t)cap * (RAY_FIELDS + 2);
-            HIP_TRY(hipMalloc(&s->stack_mem[c][k], words * sizeof(uint64_t)));
-            uint64_t *base = (uint64_t *)s->stack_mem[c][k];
+            if (s->stack_mem[c][k]) (void)hipFree(s->stack_mem[c][k]);
+            s->stack_mem[c][k] = nullptr;
+            s->stack[c][k] = RayStack{};
+        }
+}
+
+// All four stacks with `cap` slots each, or none: a failed allocation leaves the scene without
+// stacks (every cap 0), never with some of them.
+static int ensure_stacks(rt_scene *s, uint64_t cap, hipStream_t st)
+{
+    bool have = true;
+    for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) have = have && s->stack_mem[c][k] && s->stack[c][k].cap >= cap;
+    if (have) return 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    free_stacks(s);
+    const size_t words = (size_t)cap * (RAY_FIELDS + 2);
+    void *mem[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+        const hipError_t e = hipMalloc(&mem[i], words * sizeof(uint64_t));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; j++) (void)hipFree(mem[j]);
+            return fail_hip("hipMalloc (ray stacks)", e);
+        }
+    }
+    for (int c = 0; c < 2; c++)
+        for (int k = 0; k < 2; k++) {
+            s->stack_mem[c][k] = mem[2 * c + k];
+            uint64_t *base = (uint64_t *)mem[2 * c + k];
             s->stack[c][k].f = base;
             s->stack[c][k].hit_t = (double *)(base + (size_t)cap * RAY_FIELDS);
             s->stack[c][k].hit_id = base + (size_t)cap * (RAY_FIELDS + 1);
@@ -737,12 +761,9 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
         const int rc = ensure_stacks(s, cap, st);
         if (rc == 0) break;
         if (target <= (1u << 20)) return rc;
-        (void)hipGetLastError();
-        for (int c = 0; c < 2; c++)
-            for (int k = 0; k < 2; k++)
-                if (s->stack_mem[c][k]) { (void)hipFree(s->stack_mem[c][k]); s->stack_mem[c][k] = nullptr; s->stack[c][k].cap = 0; }
         target >>= 1; cap = target * (max_push + 3);
     }
+    s->failed = 0;              // a failure of an earlier call has been reported by rt_scene_check or by that call's own status
 
     uint64_t count[2][2] = {{0, 0}, {0, 0}};      // [class][side]
     int cur[2] = {0, 0};                          // side that is the class's source
@@ -772,6 +793,7 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
                 if (int rc = read_counts(n0, n1)) return rc;
                 count[0][cur[0]] += n0; count[1][cur[1]] += n1;
                 s->prof[4] += 1;
+                s->flow[0] += (double)m;
                 issued += m;
             }
         }
@@ -805,6 +827,7 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
             s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
         }
         s->prof[5] += 1;
+        s->flow[1] += (double)c; s->flow[2] += (double)n[0]; s->flow[3] += (double)n[1];
         count[X][cur[X]] -= c;
         count[X][cur[X] ^ 1] += n[X];
         count[Y][cur[Y]] += n[Y];
@@ -882,6 +905,14 @@ int rt_scene_get_profile(rt_scene *s, double out[6], int reset)
     if (!s || !out) return fail("rt_scene_get_profile: null argument");
     for (int k = 0; k < 6; k++) out[k] = s->prof[k];
     if (reset) for (int k = 0; k < 6; k++) s->prof[k] = 0;
+    return 0;
+}
+
+int rt_scene_get_ray_flow(rt_scene *s, double out[4], int reset)
+{
+    if (!s || !out) return fail("rt_scene_get_ray_flow: null argument");
+    for (int k = 0; k < 4; k++) out[k] = s->flow[k];
+    if (reset) for (int k = 0; k < 4; k++) s->flow[k] = 0;
     return 0;
 }
 
@@ -1000,12 +1031,18 @@ int rt_resolve_tone_bgr8_host(const double *radiance_sum, int w, int h, int spp,
 }
 
 // Snapshot, bmpgenerator.cpp:3-45, with fixed-width fields (the reference's `unsigned long`
-// header members are 8 bytes on LP64 and would corrupt the file).
+// header members are 8 bytes on LP64 and would corrupt the file).  The reference writes rows of
+// 3*width bytes back to back, which is a valid file only when that is a multiple of four (true of
+// every size its driver uses, main.cpp:13-23); here every row is padded to a multiple of four bytes
+// as the format requires, so the two agree byte for byte on those sizes and any other width still
+// gives a readable file.
 int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename)
 {
     if (!bgr || !filename) return fail("rt_save_bmp: null argument");
     if (width <= 0 || height <= 0) return fail("rt_save_bmp: bad size");
-    const uint32_t size = (uint32_t)width * (uint32_t)height * 3u;
+    const uint32_t row = (uint32_t)width * 3u, stride = (row + 3u) & ~3u;
+    if ((uint64_t)stride * (uint64_t)height > 0xFFFFFF00ull) return fail("rt_save_bmp: image too large for the format");
+    const uint32_t size = stride * (uint32_t)height;
     unsigned char hdr[54];
     std::memset(hdr, 0, sizeof hdr);
     auto put16 = [&](int off, uint16_t v) { hdr[off] = v & 0xff; hdr[off + 1] = v >> 8; };
@@ -1021,8 +1058,15 @@ int rt_save_bmp(const uint8_t *bgr, int width, int height, const char *filename)
     put32(34, size);             // biSizeImage
     FILE *fp = std::fopen(filename, "wb");
     if (!fp) return fail(std::string("rt_save_bmp: cannot open ") + filename);
-    bool ok = std::fwrite(hdr, 1, 54, fp) == 54 && std::fwrite(bgr, 1, size, fp) == size;
-    std::fclose(fp);
+    bool ok = std::fwrite(hdr, 1, 54, fp) == 54;
+    if (stride == row) {
+        ok = ok && std::fwrite(bgr, 1, size, fp) == size;
+    } else {
+        const unsigned char zeros[4] = {0, 0, 0, 0};
+        for (int y = 0; ok && y < height; y++)
+            ok = std::fwrite(bgr + (size_t)y * row, 1, row, fp) == row && std::fwrite(zeros, 1, stride - row, fp) == stride - row;
+    }
+    ok = (std::fclose(fp) == 0) && ok;
     return ok ? 0 : fail("rt_save_bmp: short write");
 }
 

@@ -601,6 +601,11 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
         c.rays += 1;
 #elif RT_STEP_STATS == 2
         if (mode == TM_FETCH || mode == TM_OBJ) c.rays += 1;
+#elif RT_STEP_STATS == 6
+        {   // object phases and the lanes that take part in them; node steps and their lanes below
+            const uint32_t sO = (uint32_t)__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH));
+            if (lane == 0) { c.leaf += 1; c.prim += sO; }
+        }
 #endif
         if (mode == TM_OBJ) {
             if (T.oi & RT_OI_LOCAL) {
@@ -761,6 +766,8 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 c.inner += 1;
 #elif RT_STEP_STATS == 2
                 if (mode == TM_NODE || mode == TM_POP) c.inner += 1;
+#elif RT_STEP_STATS == 6
+                if (lane == 0) { c.rays += 1; c.inner += (uint32_t)__popcll(mN); }
 #endif
                 if (mode == TM_POP) pop_now();
                 const bool in = mode == TM_NODE;
@@ -803,7 +810,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         for (uint32_t i = 0; i < RT_PRE; i++) m |= sph_pass(Q[i], rf) ? 1u << i : 0u;
                         T.pend |= (m & ((1u << take) - 1u)) << (T.k - T.pbase);
                         T.k += take;
-#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4
+#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6
                         c.prim += take;
 #endif
                         // the spheres of the records after these

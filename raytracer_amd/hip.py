@@ -20,7 +20,7 @@ EXPORTS = (
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
-    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
+    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_scene_get_ray_flow", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
     "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_open_mjpg", "rt_avi_add_frame", "rt_avi_close",
@@ -62,6 +62,7 @@ def lib():
     L.rt_scene_check.argtypes = [_vp, _vp]
     L.rt_scene_set_profiling.argtypes = [_vp, _int]
     L.rt_scene_get_profile.argtypes = [_vp, _dp, _int]
+    L.rt_scene_get_ray_flow.argtypes = [_vp, _dp, _int]
     L.rt_resolve_bgr8.argtypes = [_vp, _int, _int, _int, _vp, _vp]
     L.rt_resolve_bgr8_host.argtypes = [_vp, _int, _int, _int, _vp]
     L.rt_save_bmp.argtypes = [_vp, _int, _int, C.c_char_p]
@@ -282,6 +283,11 @@ class HipScene:
         out = (C.c_double * 6)()
         _chk(lib().rt_scene_get_profile(self._h, out, 1 if reset else 0), "rt_scene_get_profile")
         return dict(zip(("trace_launches", "trace_ms", "shade_launches", "shade_ms", "generate_launches", "rounds"), out[:]))
+
+    def get_ray_flow(self, reset=True):
+        out = (C.c_double * 4)()
+        _chk(lib().rt_scene_get_ray_flow(self._h, out, 1 if reset else 0), "rt_scene_get_ray_flow")
+        return dict(zip(("first_rays", "shaded_in", "appended_class0", "appended_class1"), out[:]))
 
     def implicit_stats(self, kind):
         out = (C.c_uint64 * 6)()

@@ -218,6 +218,15 @@ def bunny_cornell_scene(nu=186, nv=187, light="sphere", extras=False, wall_tess=
     return desc, cam
 
 
+def flythrough_camera(u, aspect):
+    """Camera at parameter u in [0, 1) of the closed fly-through curve around the Cornell box of
+    bunny_cornell_scene (in front of the open side and into it, looking at the mesh): the keyword
+    arguments of Camera(lookFrom, lookAt, vup, vfov, aspect)."""
+    a = 2 * math.pi * u
+    eye = (50 + 32 * math.cos(a), 50 + 12 * math.sin(2 * a), 185 + 45 * math.sin(a))
+    return dict(look_from=eye, look_at=(50, 38, 48), vup=(0, 1, 0), vfov=40.0, aspect=aspect)
+
+
 def smallpt_scene():
     """The nine smallpt spheres (smallpt.cpp:31-39 values) as reference Spheres; the camera sits
     inside the front wall sphere.  Needs face_forward=True: the wall spheres are seen from inside."""

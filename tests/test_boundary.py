@@ -89,6 +89,23 @@ def test_bmp_header_and_payload(tmp_path):
     assert np.array_equal(im, img[::-1, :, ::-1])
 
 
+@pytest.mark.parametrize("w", [7, 5, 2, 1])
+def test_bmp_rows_are_padded_to_four_bytes(tmp_path, w):
+    """Widths whose rows are not a multiple of four bytes: the file stays a valid 24-bit BMP (the
+    reference's unpadded rows, bmpgenerator.cpp:24-41, would shear the image) and a standard
+    reader returns the pixels."""
+    from PIL import Image
+    rng = np.random.default_rng(w)
+    img = rng.integers(0, 256, (5, w, 3), dtype=np.uint8)
+    f = tmp_path / "p.bmp"
+    hip.save_bmp(img, str(f))
+    raw = f.read_bytes()
+    stride = (3 * w + 3) & ~3
+    assert len(raw) == 54 + 5 * stride and int.from_bytes(raw[2:6], "little") == len(raw)
+    assert int.from_bytes(raw[34:38], "little") == 5 * stride
+    assert np.array_equal(np.asarray(Image.open(str(f))), img[::-1, :, ::-1])
+
+
 def test_invalid_scenes_are_rejected_before_any_device_work():
     L = hip.lib()
     good, _ = scenes.three_sphere_scene()

@@ -1,0 +1,142 @@
+"""The benchmark configurations at their own sizes, on the GPU through the C ABI:
+
+* the Sponza-class atrium at 1920 x 1080, one GPU's 128-sample slice of the 1024-spp frame
+  (n = m = 32): whole image rows against the CPU oracle, additivity of two slices, ray counts;
+* the fly-through: 1280 x 720 at 128 spp (n = 16, m = 8, so n != m), frames dealt round-robin to
+  8 ranks (main.cpp:74-100), whole rows of several frames against the oracle, the frames written
+  through the library's AviSaver path (AviSaver.cpp:24-38,57-64) and decoded back.
+
+Radiance tolerances are the north-star ones (1e-4 per path, image RMSE 1e-3); counters are exact.
+"""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from raytracer_amd import hip, scenes
+from raytracer_amd.desc import render_params
+from raytracer_amd.parallel import frame_slice, sample_slice
+
+pytestmark = pytest.mark.gpu
+
+PATH_RTOL = 1e-4
+RMSE_TOL = 1e-3
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.maximum(1e-9, np.maximum(np.abs(a), np.abs(b)))
+
+
+def _check_rows(so, cam, prm, img, rows, spp, threads=16):
+    """Whole image rows of `img` (a GPU frame or slice) against the oracle on the same samples."""
+    W = prm.width
+    oc = orc.camera_init(**cam)
+    for y in rows:
+        row, _ = so.render(oc, prm, threads=threads, pix_range=(W * y, W * y + W))
+        got, exp = img[y], row[y]
+        assert np.sqrt((((got - exp) / spp) ** 2).mean()) <= RMSE_TOL, y
+        assert (_rel(got, exp) > PATH_RTOL).mean() <= 1e-3, y
+        assert exp.mean() > 0.0, y
+
+
+def test_atrium_full_size_sample_slices():
+    """1920 x 1080, the slice [0, 128) of the n = m = 32 table that rank 0 of an 8-GPU job renders
+    (in two halves, which must add up), rows against the oracle, ray counts additive."""
+    desc, cam = scenes.atrium_scene()
+    sg, so = hip.HipScene(desc), orc.OracleScene(desc)
+    c = hip.camera_init(**cam)
+    W, H, n = 1920, 1080, 32
+    b, e = sample_slice(0, 8, n * n)
+    assert (b, e) == (0, 128)
+    acc = np.zeros((H, W, 3))
+    rays = 0
+    for lo, hi in ((b, b + 64), (b + 64, e)):
+        _, k = sg.render(c, render_params(W, H, n, sample_begin=lo, sample_end=hi, seed=1243), acc)
+        rays += int(k[0])
+    assert rays > W * H * 128 * 5
+    # rows of the 64-sample half slice and of the whole 128-sample slice against the oracle
+    _check_rows(so, cam, render_params(W, H, n, sample_begin=b, sample_end=e, seed=1243), acc, (3, 611), 128)
+    half, kh = sg.render(c, render_params(W, H, n, sample_begin=b + 64, sample_end=e, seed=1243))
+    _check_rows(so, cam, render_params(W, H, n, sample_begin=b + 64, sample_end=e, seed=1243), half, (1040,), 64)
+    # a slice from the far end of the table (rank 7's first samples) differs from rank 0's: the
+    # sampler is keyed on the global sample index
+    other, _ = sg.render(c, render_params(W, H, n, sample_begin=896, sample_end=898, seed=1243))
+    first, _ = sg.render(c, render_params(W, H, n, sample_begin=0, sample_end=2, seed=1243))
+    assert np.abs(other - first).max() > 1e-3
+    _check_rows(so, cam, render_params(W, H, n, sample_begin=896, sample_end=898, seed=1243), other, (540,), 2)
+
+
+def _avi_jpegs(raw):
+    """The JPEG frames of a Motion-JPEG AVI, in index order."""
+    movi, idx = raw.index(b"movi"), raw.rindex(b"idx1")
+    nfr = struct.unpack_from("<I", raw, idx + 4)[0] // 16
+    out = []
+    for k in range(nfr):
+        ck, _, off, sz = struct.unpack_from("<4sIII", raw, idx + 8 + 16 * k)
+        assert ck == b"00dc"
+        out.append(raw[movi + off + 8:movi + off + 8 + sz])
+    return out
+
+
+def test_flythrough_frames_round_robin_through_avi(tmp_path):
+    """Config 5 at its size: 1280 x 720, n = 16, m = 8.  Rank 3 of 8 renders its first frames of the
+    120-frame loop; rows of each against the oracle at the full 128 spp; the resolved frames go
+    through the Motion-JPEG AviSaver path and decode back to the rendered bytes."""
+    Image = pytest.importorskip("PIL.Image")
+    desc, _ = scenes.bunny_cornell_scene()
+    sg, so = hip.HipScene(desc), orc.OracleScene(desc)
+    W, H, n, m, nframes, world = 1280, 720, 16, 8, 120, 8
+    mine = frame_slice(3, world, nframes)
+    assert mine[:3] == [3, 11, 19] and len(mine) == 15
+    assert sorted(f for r in range(world) for f in frame_slice(r, world, nframes)) == list(range(nframes))
+    prm = render_params(W, H, n, m, seed=1243)
+    assert prm.sample_end == 128
+    frames = []
+    for f in mine[:3]:
+        cam = scenes.flythrough_camera(f / nframes, W / H)
+        img, k = sg.render(hip.camera_init(**cam), prm)
+        assert int(k[0]) > W * H * 128 * 3
+        _check_rows(so, cam, prm, img, (40 + 7 * f, 360, 700 - 5 * f), 128)
+        bgr = hip.resolve_bgr8_host(img, n * m)
+        assert np.array_equal(bgr, orc.resolve_bgr8(img, n * m))
+        frames.append(bgr)
+    assert np.abs(frames[0].astype(int) - frames[2].astype(int)).mean() > 1.0      # the camera moves
+    path = str(tmp_path / "fly.avi")
+    with hip.AviWriter(path, W, H, 15.0, mjpg_quality=95) as avi:                  # fourcc MJPG, 15 fps: AviSaver.cpp:57-64
+        for fr in frames:
+            avi.add(fr)
+    raw = open(path, "rb").read()
+    assert raw.count(b"vidsMJPG") == 1
+    jpgs = _avi_jpegs(raw)
+    assert len(jpgs) == len(frames)
+    for jpg, fr in zip(jpgs, frames):
+        dec = np.asarray(Image.open(io.BytesIO(jpg)).convert("RGB")).astype(float)   # top-down R,G,B
+        src = fr[::-1, :, ::-1].astype(float)                                       # AddImg flips the rows: AviSaver.cpp:31
+        assert dec.shape == src.shape
+        assert 10 * np.log10(255.0 ** 2 / max(((dec - src) ** 2).mean(), 1e-12)) > 35
+
+
+@pytest.mark.parametrize("n,m", [(5, 3), (2, 7), (1, 6)])
+def test_render_with_rectangular_jitter_table(n, m):
+    """RTObject::setRandomSize(n, m) with n != m (RTObject.cpp:23-39,53-58): pixel jitter and the
+    lights' (u, v) come from n x m strata; frames and slices against the oracle."""
+    desc, cam = scenes.bunny_cornell_scene(nu=30, nv=31, light="face", extras=True)
+    sg, so = hip.HipScene(desc), orc.OracleScene(desc)
+    c = hip.camera_init(**cam)
+    W, H = 56, 40
+    prm = render_params(W, H, n, m, seed=77)
+    i1, k1 = so.render(orc.camera_init(**cam), prm)
+    i2, k2 = sg.render(c, prm)
+    assert np.array_equal(k1, k2)
+    assert _rel(i1, i2).max() <= PATH_RTOL and np.sqrt((((i1 - i2) / (n * m)) ** 2).mean()) <= RMSE_TOL
+    acc = np.zeros_like(i2)
+    cut = (n * m) // 2
+    sg.render(c, render_params(W, H, n, m, sample_begin=0, sample_end=cut, seed=77), acc)
+    sg.render(c, render_params(W, H, n, m, sample_begin=cut, sample_end=n * m, seed=77), acc)
+    assert np.allclose(acc, i2, rtol=1e-12, atol=1e-14)
+    # the transposed table is a different set of strata
+    if n != m:
+        i3, _ = sg.render(c, render_params(W, H, m, n, seed=77))
+        assert np.abs(i3 - i2).max() > 1e-6

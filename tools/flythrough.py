@@ -12,7 +12,6 @@ rendering); rank 0 gathers the 8-bit frames and writes them, in order, into an A
 library's writer.  Prints one JSON line: frames/s and Mrays/s of the whole job."""
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -32,9 +31,7 @@ from raytracer_amd.parallel import dist_env, render_frames  # noqa: E402
 
 def camera_on_path(u, aspect):
     """Camera at parameter u in [0, 1) of the closed curve."""
-    a = 2 * math.pi * u
-    eye = (50 + 32 * math.cos(a), 50 + 12 * math.sin(2 * a), 185 + 45 * math.sin(a))
-    return hip.camera_init(eye, (50, 38, 48), (0, 1, 0), 40.0, aspect)
+    return hip.camera_init(**scenes.flythrough_camera(u, aspect))
 
 
 def main():

@@ -1,12 +1,14 @@
 #!/bin/bash
-# Profiles bench.py on the GPU box: kernel-trace stats, then separate PMC passes for HBM bytes.
-# Outputs land in gpurun_out/prof_bench/ ; tools/summarize_profile.py turns them into profiles/.
+# Profiles bench.py on the GPU box: kernel-trace stats, then separate PMC passes (HBM bytes, SQ
+# counters).  usage: tools/profile_bench.sh [bunny|atrium]
+# Outputs land in gpurun_out/prof_<workload>/ ; tools/summarize_profile.py turns them into profiles/.
 set -e
+W=${1:-bunny}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_bench
+O=$R/gpurun_out/prof_$W
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline"
+ARGS="--workload $W --steps 1 --warmup 0 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py $ARGS > $O/stats.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
