@@ -56,6 +56,12 @@ def _mesh_desc(tris, **kw):
                      [tris], **kw)
 
 
+def _bmp_pixels(raw, W, H):
+    """The (H, W, 3) payload of a 24-bit BMP whose rows are padded to four bytes."""
+    stride = (3 * W + 3) & ~3
+    return np.frombuffer(raw[54:], np.uint8).reshape(H, stride)[:, :3 * W].reshape(H, W, 3)
+
+
 def _example(name):
     """Path of a built program under examples/ (built here with g++ if the tree came without it)."""
     import subprocess
@@ -444,7 +450,7 @@ def test_cpp_scene_api_example_matches_oracle(tmp_path):
     out = str(tmp_path / "k.bmp")
     subprocess.check_call([exe, str(W), str(H), str(n), out], timeout=120)
     raw = open(out, "rb").read()
-    got = np.frombuffer(raw[54:], np.uint8).reshape(H, W, 3)
+    got = _bmp_pixels(raw, W, H)
     desc, cam = scenes.kaleidoscope_scene(W, H)
     so = orc.OracleScene(desc)
     img, _ = so.render(orc.camera_init(**cam), render_params(W, H, n, seed=1243))
@@ -518,7 +524,7 @@ def test_cpp_animation_example_matches_oracle(tmp_path):
     prev = None
     for f, time in enumerate(frame_times(nframes)):
         raw = open(tmp_path / f"f_{f:03d}.bmp", "rb").read()
-        got = np.frombuffer(raw[54:], np.uint8).reshape(H, W, 3)
+        got = _bmp_pixels(raw, W, H)
         desc.lights[li] = orc.light_move_face(l0, time)
         img, _ = orc.OracleScene(desc).render(orc.camera_change_fov(c0, time), render_params(W, H, n, seed=1243))
         exp = orc.resolve_bgr8(img, n * n)
