@@ -220,6 +220,18 @@ int rt_ray_color(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, dou
 int rt_ray_color_host(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, double t1,
                       int jumptime, const rt_render_params *params, double *out, uint64_t *counters);
 
+/* rt_ray_color for callers that cannot allocate device memory (code that must not call hipMalloc:
+ * tight serving loops, harnesses that forbid it).  It has no counterpart in the reference.  Same
+ * arguments, results and counters as rt_ray_color (device pointers, returns when the work on
+ * `stream` is complete), but the pending-ray stacks and control words live in a 64 MiB static
+ * device array that every GPU the library runs on holds until the process ends, and the call makes
+ * no hipMalloc, hipFree or allocating library call.  Limits: n <= 1 048 576 rays per call
+ * (rejected beyond that).  All calls on one GPU share that GPU's workspace, whatever scene they
+ * name: calls that overlap on one GPU race. */
+int rt_ray_color_noalloc(rt_scene *scene, const rt_ray *rays, uint64_t n, double t0, double t1,
+                         int jumptime, const rt_render_params *params, double *out, uint64_t *counters,
+                         void *stream);
+
 /* Scene::run / runParallelly (scene.cpp:95-172) for every pixel and the sample slice
  * [sample_begin, sample_end): radiance_sum[y][x][3] += sum of rayColor over the slice
  * (not divided, not clamped -- the clamp comes after averaging, scene.cpp:112-113, so

@@ -730,6 +730,90 @@ static int ensure_stacks(rt_scene *s, uint64_t cap, hipStream_t st)
     return 0;
 }
 
+// The device memory one run of the pipeline works in: four ray stacks of `cap` slots ([class][side])
+// and the control words (see rt_scene::d_ctrl); `target` = rays per round.
+struct WaveSpace {
+    RayStack stack[2][2];
+    uint32_t *d_ctrl;
+    uint64_t cap, target;
+};
+
+static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_t total_items, hipStream_t st)
+{
+    const uint64_t max_push = (uint64_t)s->max_push, cap = ws.cap, target = ws.target;
+    uint32_t *const d_ctrl = ws.d_ctrl;
+    s->failed = 0;              // a failure of an earlier call has been reported by rt_scene_check or by that call's own status
+    uint64_t count[2][2] = {{0, 0}, {0, 0}};      // [class][side]
+    int cur[2] = {0, 0};                          // side that is the class's source
+    uint64_t issued = 0;
+    // how many rays each class received from the kernel that has just been enqueued
+    auto read_counts = [&](uint64_t &n0, uint64_t &n1) -> int {
+        HIP_TRY(hipMemcpyAsync(s->h_ctrl, d_ctrl, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n0 = s->h_ctrl[0]; n1 = s->h_ctrl[1];
+        return 0;
+    };
+    for (;;) {
+        for (int c = 0; c < 2; c++) if (count[c][cur[c]] == 0 && count[c][cur[c] ^ 1] != 0) cur[c] ^= 1;
+        uint64_t have = count[0][cur[0]] > count[1][cur[1]] ? count[0][cur[0]] : count[1][cur[1]];
+        // top up with first rays
+        if (issued < total_items && have < target) {
+            uint64_t m = target - have;
+            if (m > total_items - issued) m = total_items - issued;
+            for (int c = 0; c < 2; c++) if (m > cap - count[c][cur[c]]) m = cap - count[c][cur[c]];
+            if (m) {
+                RayDest D;
+                for (int c = 0; c < 2; c++) { D.q[c] = ws.stack[c][cur[c]]; D.base[c] = count[c][cur[c]]; }
+                D.count = d_ctrl;
+                HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));
+                HIP_TRY(launch_generate(s->dev, A, D, issued, (uint32_t)m, st));
+                uint64_t n0, n1;
+                if (int rc = read_counts(n0, n1)) return rc;
+                count[0][cur[0]] += n0; count[1][cur[1]] += n1;
+                s->prof[4] += 1;
+                s->flow[0] += (double)m;
+                issued += m;
+            }
+        }
+        const int X = count[0][cur[0]] > count[1][cur[1]] ? 0 : 1, Y = X ^ 1;
+        if (count[X][cur[X]] == 0) {
+            if (issued < total_items) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+            break;
+        }
+        uint64_t c = count[X][cur[X]] < target ? count[X][cur[X]] : target;
+        const uint64_t roomX = (cap - count[X][cur[X] ^ 1]) / max_push, roomY = (cap - count[Y][cur[Y]]) / max_push;
+        if (c > roomX) c = roomX;
+        if (c > roomY) c = roomY;
+        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+        const uint64_t base = count[X][cur[X]] - c;
+        RayDest D;
+        D.q[X] = ws.stack[X][cur[X] ^ 1]; D.base[X] = count[X][cur[X] ^ 1];
+        D.q[Y] = ws.stack[Y][cur[Y]];     D.base[Y] = count[Y][cur[Y]];
+        D.count = d_ctrl;
+        HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+        HIP_TRY(launch_trace(s->dev, s->num_cu, d_ctrl + 2, A, ws.stack[X][cur[X]], base, (uint32_t)c, X, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
+        HIP_TRY(launch_shade(s->dev, A, ws.stack[X][cur[X]], base, (uint32_t)c, D, st));
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
+        uint64_t n[2];
+        if (int rc = read_counts(n[0], n[1])) return rc;
+        if (s->profiling) {
+            float a = 0, b = 0;
+            HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+            s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
+        }
+        s->prof[5] += 1;
+        s->flow[1] += (double)c; s->flow[2] += (double)n[0]; s->flow[3] += (double)n[1];
+        count[X][cur[X]] -= c;
+        count[X][cur[X] ^ 1] += n[X];
+        count[Y][cur[Y]] += n[Y];
+        if (n[X]) cur[X] ^= 1;
+    }
+    return 0;
+}
+
 static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStream_t st)
 {
     if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
@@ -763,77 +847,10 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
         if (target <= (1u << 20)) return rc;
         target >>= 1; cap = target * (max_push + 3);
     }
-    s->failed = 0;              // a failure of an earlier call has been reported by rt_scene_check or by that call's own status
-
-    uint64_t count[2][2] = {{0, 0}, {0, 0}};      // [class][side]
-    int cur[2] = {0, 0};                          // side that is the class's source
-    uint64_t issued = 0;
-    // appends `what` (a kernel launch that fills dst) and adds the per-class counts to `to`
-    auto read_counts = [&](uint64_t &n0, uint64_t &n1) -> int {
-        HIP_TRY(hipMemcpyAsync(s->h_ctrl, s->d_ctrl, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        n0 = s->h_ctrl[0]; n1 = s->h_ctrl[1];
-        return 0;
-    };
-    for (;;) {
-        for (int c = 0; c < 2; c++) if (count[c][cur[c]] == 0 && count[c][cur[c] ^ 1] != 0) cur[c] ^= 1;
-        uint64_t have = count[0][cur[0]] > count[1][cur[1]] ? count[0][cur[0]] : count[1][cur[1]];
-        // top up with first rays
-        if (issued < total_items && have < target) {
-            uint64_t m = target - have;
-            if (m > total_items - issued) m = total_items - issued;
-            for (int c = 0; c < 2; c++) if (m > cap - count[c][cur[c]]) m = cap - count[c][cur[c]];
-            if (m) {
-                RayDest D;
-                for (int c = 0; c < 2; c++) { D.q[c] = s->stack[c][cur[c]]; D.base[c] = count[c][cur[c]]; }
-                D.count = s->d_ctrl;
-                HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 8, st));
-                HIP_TRY(launch_generate(s->dev, A, D, issued, (uint32_t)m, st));
-                uint64_t n0, n1;
-                if (int rc = read_counts(n0, n1)) return rc;
-                count[0][cur[0]] += n0; count[1][cur[1]] += n1;
-                s->prof[4] += 1;
-                s->flow[0] += (double)m;
-                issued += m;
-            }
-        }
-        const int X = count[0][cur[0]] > count[1][cur[1]] ? 0 : 1, Y = X ^ 1;
-        if (count[X][cur[X]] == 0) {
-            if (issued < total_items) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
-            break;
-        }
-        uint64_t c = count[X][cur[X]] < target ? count[X][cur[X]] : target;
-        const uint64_t roomX = (cap - count[X][cur[X] ^ 1]) / max_push, roomY = (cap - count[Y][cur[Y]]) / max_push;
-        if (c > roomX) c = roomX;
-        if (c > roomY) c = roomY;
-        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
-        const uint64_t base = count[X][cur[X]] - c;
-        RayDest D;
-        D.q[X] = s->stack[X][cur[X] ^ 1]; D.base[X] = count[X][cur[X] ^ 1];
-        D.q[Y] = s->stack[Y][cur[Y]];     D.base[Y] = count[Y][cur[Y]];
-        D.count = s->d_ctrl;
-        HIP_TRY(hipMemsetAsync(s->d_ctrl, 0, 8, st));
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
-        HIP_TRY(launch_trace(s->dev, s->num_cu, s->d_ctrl + 2, A, s->stack[X][cur[X]], base, (uint32_t)c, X, st));
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
-        HIP_TRY(launch_shade(s->dev, A, s->stack[X][cur[X]], base, (uint32_t)c, D, st));
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
-        uint64_t n[2];
-        if (int rc = read_counts(n[0], n[1])) return rc;
-        if (s->profiling) {
-            float a = 0, b = 0;
-            HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
-            HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
-            s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
-        }
-        s->prof[5] += 1;
-        s->flow[1] += (double)c; s->flow[2] += (double)n[0]; s->flow[3] += (double)n[1];
-        count[X][cur[X]] -= c;
-        count[X][cur[X] ^ 1] += n[X];
-        count[Y][cur[Y]] += n[Y];
-        if (n[X]) cur[X] ^= 1;
-    }
-    return 0;
+    WaveSpace ws;
+    for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) ws.stack[c][k] = s->stack[c][k];
+    ws.d_ctrl = s->d_ctrl; ws.cap = cap; ws.target = target;
+    return wavefront_loop(s, ws, A, total_items, st);
 }
 
 static int fill_args(const rt_render_params *p, WaveArgs &A, bool batch)
@@ -864,6 +881,51 @@ int rt_ray_color(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double 
     A.out = out; A.counters = counters;
     if (n) HIP_TRY(hipMemsetAsync(out, 0, n * 3 * sizeof(double), (hipStream_t)stream));
     return run_wavefront(s, A, n, (hipStream_t)stream);
+}
+
+// rt_ray_color with its ray stacks and control words in the library's static device workspace
+// instead of allocated memory: no hipMalloc / hipFree and no allocating library call is made.
+// Every call on a device uses that device's one workspace (the stacks' contents need no clearing:
+// the host tracks how many slots of each are live; the control words are zeroed before every
+// kernel that counts into them), so calls that overlap on one device race.
+int rt_ray_color_noalloc(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double t1, int jumptime, const rt_render_params *p,
+                         double *out, uint64_t *counters, void *stream)
+{
+    if (!s) return fail("rt_ray_color_noalloc: null scene");
+    if (n && (!rays || !out)) return fail("rt_ray_color_noalloc: null buffer");
+    if (n > RT_NOALLOC_MAX_RAYS) return fail("rt_ray_color_noalloc: at most 1048576 rays per call (the static workspace is sized for that)");
+    if (jumptime < 0 || jumptime > 60) return fail("rt_ray_color_noalloc: jumptime must be in [0,60]");
+    WaveArgs A;
+    if (int rc = fill_args(p, A, true)) return rc;
+    if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    void *base = nullptr;
+    HIP_TRY(static_scratch(&base));
+    // 256 bytes of control words, then four stacks of `cap` slots of (RAY_FIELDS + 2) words
+    const uint64_t max_push = (uint64_t)s->max_push;
+    const uint64_t slot_bytes = (RAY_FIELDS + 2) * sizeof(uint64_t);
+    const uint64_t stack_bytes = (((uint64_t)RT_STATIC_SCRATCH_BYTES - 256u) / 4u) & ~(uint64_t)255u;
+    const uint64_t cap = (stack_bytes / slot_bytes) & ~(uint64_t)63u;
+    uint64_t target = cap / (max_push + 3);
+    if (target < RT_BLOCK) return fail("rt_ray_color_noalloc: the scene's materials and lights append more rays per hit than the static workspace holds");
+    if (target > n * max_push) target = n * max_push;
+    if (target < RT_BLOCK) target = RT_BLOCK;
+    WaveSpace ws;
+    ws.d_ctrl = (uint32_t *)base;
+    for (int c = 0; c < 2; c++)
+        for (int k = 0; k < 2; k++) {
+            uint64_t *m = (uint64_t *)((unsigned char *)base + 256 + (uint64_t)(2 * c + k) * stack_bytes);
+            ws.stack[c][k].f = m;
+            ws.stack[c][k].hit_t = (double *)(m + cap * RAY_FIELDS);
+            ws.stack[c][k].hit_id = m + cap * (RAY_FIELDS + 1);
+            ws.stack[c][k].cap = cap;
+        }
+    ws.cap = cap; ws.target = target;
+    A.batch = 1; A.rays = rays; A.t0 = t0; A.t1 = t1; A.jumptime = jumptime;
+    A.out = out; A.counters = counters;
+    HIP_TRY(hipMemsetAsync(out, 0, n * 3 * sizeof(double), (hipStream_t)stream));
+    return wavefront_loop(s, ws, A, n, (hipStream_t)stream);
 }
 
 int rt_render(rt_scene *s, const rt_camera *cam, const rt_render_params *p, double *radiance_sum, uint64_t *counters, void *stream)

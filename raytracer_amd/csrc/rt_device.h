@@ -100,6 +100,11 @@ struct RayDest {
     uint32_t *count;        // count[0], count[1]: rays appended by the running kernel (zeroed by the host)
 };
 
+// The workspace of the entry point that allocates nothing (rt_ray_color_noalloc): a file-scope
+// device array of this many bytes, 256 bytes of control words followed by the four ray stacks.
+#define RT_STATIC_SCRATCH_BYTES ((64u << 20) + 256u)
+#define RT_NOALLOC_MAX_RAYS (1u << 20)
+
 struct WaveArgs {
     rt_camera cam;
     int32_t  width, height;

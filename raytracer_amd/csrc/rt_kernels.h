@@ -19,6 +19,10 @@ hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const Wav
                         int ray_class, hipStream_t st);
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
                         const RayDest &dst, hipStream_t st);
+// Address, on the CURRENT device, of the library's static workspace (RT_STATIC_SCRATCH_BYTES bytes,
+// 256-byte aligned; every device holds its own copy from the moment the code object is loaded there
+// until the process ends).  Looked up once per device; no allocation is made.
+hipError_t static_scratch(void **ptr);
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, int tone, uint8_t *bgr, hipStream_t st);
 
 } // namespace rt

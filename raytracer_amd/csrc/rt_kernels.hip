@@ -7,6 +7,8 @@
 // and of std::min / std::max is kept literally.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "rt_device.h"
 #include "rt_kernels.h"
 
@@ -1624,6 +1626,35 @@ hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &sr
     }
     return hipGetLastError();
 }
+// ------------------------------------------------------------------ static workspace
+// Device memory that exists without an allocation call, for callers that may not make one: each
+// device that loads this code object holds its own copy of the array, at its own address.  In host
+// code the array's name only stands for the symbol; the address on a device comes from
+// hipGetSymbolAddress with that device current, and that address (never the name) is what kernels,
+// memsets and copies are given.
+static __device__ __attribute__((used)) __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+hipError_t static_scratch(void **ptr)
+{
+    enum { MAX_DEVICES = 64 };
+    static std::mutex mu;
+    static void *addr[MAX_DEVICES] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!addr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        addr[dev] = p;
+    }
+    *ptr = addr[dev];
+    return hipSuccess;
+}
+
 hipError_t launch_resolve(const double *sum, uint64_t npix, int spp, int tone, uint8_t *bgr, hipStream_t st)
 {
     if (npix == 0) return hipSuccess;

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")  
 EXPORTS = (
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
-    "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_render",
+    "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_ray_color_noalloc", "rt_render",
     "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_scene_get_ray_flow", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
@@ -56,6 +56,7 @@ def lib():
     L.rt_trace_primary.argtypes = [_vp, C.POINTER(CameraC), _int, _int, _vp, _vp, _vp, _vp]
     L.rt_trace_primary_host.argtypes = [_vp, C.POINTER(CameraC), _int, _int, _vp, _vp, _vp]
     L.rt_ray_color.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _int, C.POINTER(RenderParamsC), _vp, _vp, _vp]
+    L.rt_ray_color_noalloc.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _int, C.POINTER(RenderParamsC), _vp, _vp, _vp]
     L.rt_ray_color_host.argtypes = [_vp, _vp, _u64, _dbl, _dbl, _int, C.POINTER(RenderParamsC), _vp, _vp]
     L.rt_render.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _vp, _vp, _vp]
     L.rt_render_host.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _vp, _vp]
