@@ -530,7 +530,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         const double inv = 1 / std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
         for (int k = 0; k < 3; k++) tri_normals[3 * i + k] = n[k] * inv;
     }
-    // spare spheres at the end: the kernels fetch a step's spheres (at most RT_SPH_SPARE) without clamping
+    // spare spheres at the end: the kernels fetch a chunk of RT_SPH_SPARE spheres from any record on without clamping
     std::vector<uint32_t> leaf_sph((leaf_tris.size() + RT_SPH_SPARE) * RT_SPH_WORDS);
     for (size_t i = 0; i < leaf_tris.size() + RT_SPH_SPARE; i++) store_whole_node_sphere(&leaf_sph[i * RT_SPH_WORDS]);
     for (FlatNode &n : nodes) {

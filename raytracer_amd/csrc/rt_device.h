@@ -22,7 +22,7 @@ namespace rt {
 #define RT_SPH_EDGE (127u << (RT_SPH_BITS - 8))
 #define RT_SPH_ORG (64u << (RT_SPH_BITS - 8))
 #define RT_SPH_MID (128u << (RT_SPH_BITS - 8))
-#define RT_SPH_SPARE 16          // spare spheres after the last record
+#define RT_SPH_SPARE 64          // spare spheres after the last record: a chunk of 64 is read from any record on without clamping
 
 // One Group child as the kernels see it.  The object phase of the closest-hit engine reads
 // this table at wave-uniform addresses (scalar loads); a record carries everything that phase

@@ -313,10 +313,6 @@ struct TravState {
     uint32_t k, kend, bprim;
     double bt0, tempt;
     bool leaf;
-    // pre-tested triangles waiting for the fp64 test: bit j of pend = record pbase + j (a queue
-    // that several pre-test batches feed); cand = the record requested in the previous step
-    // (RT_MISS: none)
-    uint32_t pend, pbase, cand;
 };
 
 // hitBox for a ray with regular direction: same values as hit_box (FAST node steps, above)
@@ -451,32 +447,48 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         const float sc = __uint_as_float(nd_pad & ~1u);
         const float gx = (float)((e.x + d.x * n0) - lo0) * sc + (float)RT_SPH_ORG, gy = (float)((e.y + d.y * n0) - lo1) * sc + (float)RT_SPH_ORG;
         const float gz = (float)((e.z + d.z * n0) - lo2) * sc + (float)RT_SPH_ORG;
-        rayf[0][tid] = make_float4(gx, gy, gz, rayf[0][tid].w);
-        rayf[1][tid].w = 4e-7f * (fabsf(gx) + fabsf(gy) + fabsf(gz)) + 2e-4f * (float)(RT_SPH_EDGE / 127u);
+        const float4 fu = rayf[0][tid], fv = rayf[1][tid];
+        rayf[0][tid].w = -__builtin_fmaf(gx, fu.x, __builtin_fmaf(gy, fu.y, gz * fu.z));
+        rayf[1][tid].w = -__builtin_fmaf(gx, fv.x, __builtin_fmaf(gy, fv.y, gz * fv.z));
     }
 }
 
-// Triangle runs are walked RT_PRE records per step with a cheap pre-test: a single-precision
-// test of the ray against the record's bounding sphere decides whether the 80-byte record is
-// fetched and the fp64 test made at all.  The spheres are small integers in the grid of the node
-// that owns the run (see RT_SPH_BITS: with 8 bits a sphere is one word and a 16-byte load brings
-// four), rounded outwards at build time, and the test carries margins for every single-precision
-// rounding (the ray's entry point and direction, the cancellation in c2 - b^2/dd), so it only ever
-// rejects rays that pass the primitive at a clear distance: the fp64 test, which accepts rays
-// within ~1e-15 of the triangle, would reject them too.  A NaN or an overflow anywhere makes the
-// pre-test pass.  A step's fixed cost (the candidate's fp64 test, bookkeeping, the vote on the
-// next step kind) is spread over RT_PRE records, and a record costs a quarter of a load plus five
-// for the few that pass, instead of five for every record.
-// RayF is the lane's ray for that test: ex..ez = the point where the ray enters the node's box,
-// in the node's grid (written when the run opens), dx..dz = the direction in single precision.
-struct RayF { float ex, ey, ez, dx, dy, dz, inv_dd, slack; };
-__device__ __forceinline__ RayF ray_single(V3 e, V3 d)
+// The sphere pre-test.  A single-precision test of the ray against a record's bounding sphere
+// decides whether the 80-byte record is fetched and the fp64 test made at all.  The spheres are
+// small integers in the grid of the node that owns the run (see RT_SPH_BITS: with 8 bits a sphere
+// is one word and a 16-byte load brings four), rounded outwards at build time.
+// The distance of a sphere's centre c from the ray's line is measured in a frame of the ray: with
+// unit vectors u, v that span the plane perpendicular to the direction, and g a point of the ray,
+//     pu = (c - g).u ,  pv = (c - g).v ,  distance^2 = pu^2 + pv^2
+// -- two short sums of products with no cancellation between large terms (the old form
+// |c - g|^2 - ((c - g).d)^2 / |d|^2 subtracts two numbers of the size of |c - g|^2).  Errors: the
+// entry point g and the direction are rounded to single precision (g <= 256 units: 2e-5; direction
+// 6e-8 rad over at most 450 units: 3e-5), u and v are unit and perpendicular to within 2e-7
+// (1e-4 over 450 units), each sum rounds three products of up to 300 units (1e-4): under 5e-4 grid
+// units in all; RT_SPH_SLACK = 4e-3 units is added to every radius.  So the test only rejects rays
+// that pass the primitive at a clear distance: the fp64 test, which accepts rays within ~1e-15 of
+// the triangle, would reject them too.  A NaN or an overflow anywhere makes the pre-test pass.
+// RayF is the lane's ray for that test: u, v (written whenever the ray's direction changes) and
+// nu = -g.u, nv = -g.v for the point g where the ray enters the node's box, in the node's grid
+// (written when a run opens).
+#define RT_SPH_SLACK (4e-3f * (float)(RT_SPH_EDGE / 127u))
+struct RayF { float ux, uy, uz, nu, vx, vy, vz, nv; };
+__device__ __forceinline__ RayF ray_single(V3 d)
 {
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz)));
+    const float nx = dx * inv, ny = dy * inv, nz = dz * inv;
+    const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
+    // u = (axis of the smallest direction component) x n, normalised: |axis x n|^2 = 1 - n_axis^2 >= 2/3
+    float ux, uy, uz;
+    if (ax <= ay && ax <= az) { ux = 0.0f; uy = -nz; uz = ny; }
+    else if (ay <= az)        { ux = nz; uy = 0.0f; uz = -nx; }
+    else                      { ux = -ny; uy = nx; uz = 0.0f; }
+    const float iu = __builtin_amdgcn_rsqf(__builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz)));
+    ux *= iu; uy *= iu; uz *= iu;
     RayF r;
-    r.ex = (float)e.x; r.ey = (float)e.y; r.ez = (float)e.z;
-    r.dx = (float)d.x; r.dy = (float)d.y; r.dz = (float)d.z;
-    r.inv_dd = __builtin_amdgcn_rcpf(__builtin_fmaf(r.dx, r.dx, __builtin_fmaf(r.dy, r.dy, r.dz * r.dz)));   // 1 ulp, inside the margins
-    r.slack = 0.0f;
+    r.ux = ux; r.uy = uy; r.uz = uz; r.nu = 0.0f;
+    r.vx = ny * uz - nz * uy; r.vy = nz * ux - nx * uz; r.vz = nx * uy - ny * ux; r.nv = 0.0f;       // n x u
     return r;
 }
 struct SphQ { uint32_t w[RT_SPH_WORDS]; };
@@ -487,48 +499,313 @@ __device__ __forceinline__ bool sph_pass(const SphQ &q, const RayF &r)
 #else
     const float sx = (float)(q.w[0] & 0xFFFFu), sy = (float)(q.w[0] >> 16), sz = (float)(q.w[1] & 0xFFFFu), sr = (float)(q.w[1] >> 16);
 #endif
-    const float ox = sx - r.ex, oy = sy - r.ey, oz = sz - r.ez;
-    const float b = __builtin_fmaf(ox, r.dx, __builtin_fmaf(oy, r.dy, oz * r.dz));
-    const float c2 = __builtin_fmaf(ox, ox, __builtin_fmaf(oy, oy, oz * oz));
-    const float perp2 = __builtin_fmaf(-(b * r.inv_dd), b, c2);          // squared distance of the centre from the ray's line
-    const float R = sr + r.slack;
-    const float bound = __builtin_fmaf(R, R, 4e-6f * c2);
-    return !(perp2 > bound);
+    const float pu = __builtin_fmaf(sx, r.ux, __builtin_fmaf(sy, r.uy, __builtin_fmaf(sz, r.uz, r.nu)));
+    const float pv = __builtin_fmaf(sx, r.vx, __builtin_fmaf(sy, r.vy, __builtin_fmaf(sz, r.vz, r.nv)));
+    const float perp2 = __builtin_fmaf(pv, pv, pu * pu);                 // squared distance of the centre from the ray's line
+    const float R = sr + RT_SPH_SLACK;
+    return !(perp2 > R * R);
 }
-// The spheres of records k .. k+RT_PRE-1 (a run shorter than that reads into the records that
-// follow it, which are masked out when tested; the array ends with RT_PRE spare spheres).
-__device__ __forceinline__ void sph_fetch(const DevScene &S, uint32_t k, SphQ (&Q)[RT_PRE])
+// ------------------------------------------------------------------ the cooperative triangle phase
+// OctreeNode::hit (octree.cpp:19-38) for every lane of the wave that has a run open (an "owner"),
+// done by the whole wave at once instead of by each lane for itself:
+//   1. segments: every owner cuts its run into segments of RT_SEG records and lists them in the
+//      wave's segment table in LDS (a prefix sum over the owners' segment counts gives each its
+//      place), so that the work of all owners lies in one dense list;
+//   2. pre-test: a chunk = 64 / RT_SEG consecutive segments; every lane takes ONE record of its
+//      segment, tests the record's sphere against the segment owner's ray (read from LDS, where the
+//      owner left it when the run opened) and the lanes whose record passes append (record, owner)
+//      to the wave's candidate list in LDS (ballot + popcount);
+//   3. test: every lane takes one candidate, fetches its 80-byte record and the owner's fp64 ray
+//      and window (cross-lane reads) and makes the fp64 primitive test -- up to 64 candidates of
+//      different owners per pass;
+//   4. per owner the pass keeps the smallest hit distance (an LDS minimum over order-preserving
+//      integer keys) and, among the candidates that reached it, the last one in list order (an LDS
+//      maximum over list positions): OctreeNode::hit accepts a hit with `t <= tempt`, so of equal
+//      distances the later primitive wins (octree.cpp:31), and a hit farther than an earlier one
+//      never survives -- the same outcome as testing the owner's candidates one after the other.
+// The wave's cost follows the number of records it serves, not its longest run, and the fp64 tests
+// of all owners share their instructions.
+#ifndef RT_CAND_CAP
+#define RT_CAND_CAP 128          // candidate slots per wave (a ring; a power of two, at least 64)
+#endif
+#ifndef RT_SEG
+#define RT_SEG 16                // records per segment (a power of two, at most 64)
+#endif
+#define RT_LANE_RECS 4           // records a lane pre-tests per chunk (their spheres are one 16-byte load)
+#ifndef RT_SEG_CAP
+#define RT_SEG_CAP 128           // segment table entries per wave: RT_SEG_CAP * RT_SEG records are scheduled per round
+#endif
+#define RT_SEG_ROUND_MAX 15      // most segments one owner lists per round (4 bits in the prefix sum)
+struct CoopLds {                 // per wave
+    uint64_t seg[RT_SEG_CAP];    // first record | owner lane << 32 | records in the segment << 40
+    uint32_t crec[RT_CAND_CAP];  // candidate's record index
+    uint8_t  cown[RT_CAND_CAP];  // candidate's owner lane
+    unsigned long long okey[64]; // per owner lane, per pass: smallest hit distance as an ordered integer
+    uint32_t owin[64];           //   list position + 1 of the last candidate that reached it
+    uint32_t oid[64];            //   that candidate's primitive id
+};
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+// doubles (no NaN) <-> unsigned integers in the same order
+__device__ __forceinline__ unsigned long long ordered_key(double t)
 {
-    static_assert((RT_PRE * RT_SPH_WORDS) % 4 == 0 && RT_PRE <= RT_SPH_SPARE && RT_PRE <= 16, "spheres are fetched 16 bytes to a load");
-    const uint32_t *P = S.leaf_sph + (size_t)k * RT_SPH_WORDS;
-    uint32_t *out = &Q[0].w[0];
+    const unsigned long long u = (unsigned long long)__double_as_longlong(t);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ordered_value(unsigned long long k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &mode, const double *run_bt1,
+                                          const float4 (*rayf)[BLOCK], CoopLds &L, Counters &c)
+{
+    static_assert(RT_SPH_WORDS == 1, "one word per sphere: a chunk's spheres are one dword per lane");
+    static_assert((RT_CAND_CAP & (RT_CAND_CAP - 1)) == 0 && RT_CAND_CAP >= 64, "candidate ring");
+    static_assert((RT_SEG & (RT_SEG - 1)) == 0 && RT_SEG <= 64 && RT_SEG <= RT_SPH_SPARE, "segment size");
+    // a chunk = RT_LANE_RECS consecutive records per lane, RT_SEG / RT_LANE_RECS lanes to a segment
+    constexpr uint32_t LANES_PER_SEG = RT_SEG / RT_LANE_RECS, SEGS_PER_CHUNK = 64u / LANES_PER_SEG;
+    static_assert(RT_LANE_RECS == 4 && RT_SEG % RT_LANE_RECS == 0, "a lane's spheres are one 16-byte load");
+    const uint32_t lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t sub = (lane % LANES_PER_SEG) * RT_LANE_RECS, sseg = lane / LANES_PER_SEG;     // the lane's place in a chunk
+    uint32_t produced = 0, tested = 0;                 // candidates appended / tested so far (wave-uniform)
+    const bool owner = mode == TM_TRI;
+    uint32_t kcur = T.k;                               // first record of the owner's run that is not scheduled yet
+
+#if RT_STEP_STATS == 8 || RT_STEP_STATS == 9
+    long long tk8 = clock64();
+#define RT_TICK8(field) { const long long t_ = clock64(); if (lane == 0) c.field += (uint32_t)((t_ - tk8) >> 4); tk8 = t_; }
+#else
+#define RT_TICK8(field)
+#endif
+#if RT_STEP_STATS == 9
+#undef RT_TICK8
+#define RT_TICK8(field)
+#define RT_TICK9(field) { const long long t_ = clock64(); if (lane == 0) c.field += (uint32_t)((t_ - tk8) >> 4); tk8 = t_; }
+#else
+#define RT_TICK9(field)
+#endif
+    // steps 3 and 4 for everything appended so far
+    auto test_all = [&]() {
+        RT_TICK8(inner)
+        while (tested != produced) {
+#if RT_STEP_STATS == 8
+            const long long tp0 = clock64();
+#endif
+            const uint32_t left = produced - tested, n = left < 64u ? left : 64u;
+            const bool act = lane < n;
+            const uint32_t slot = (tested + lane) & (RT_CAND_CAP - 1u);
+            L.okey[lane] = ~0ull; L.owin[lane] = 0u;
+            const uint32_t rec = act ? L.crec[slot] : 0u;
+            const int o = act ? (int)L.cown[slot] : (int)lane;
+            TriReg R = {};
+            if (act) R = tri_load(S.leaf_tris + rec);
+            // the owner's ray and window (all lanes take part in the cross-lane reads)
+            const V3 e = mk(shfl_d(T.e.x, o), shfl_d(T.e.y, o), shfl_d(T.e.z, o));
+            const V3 d = mk(shfl_d(T.d.x, o), shfl_d(T.d.y, o), shfl_d(T.d.z, o));
+            const double bt0 = shfl_d(T.bt0, o), tempt = shfl_d(T.tempt, o);
+            const int fast = __shfl((int)T.fast, o, 64);
+            bool hit = false;
+            double tt = 0;
+            uint32_t id = R.id;
+            if (act) {
+                if (R.id & LEAF_VOXEL) {
+                    // BoxNode::calHit, Surface.cpp:43-59: the slab test runs on the node's whole window
+                    // [bt0, bt1], the hit is the entry point moved back along the ray by the diagonal
+                    // and is kept if it is not beyond the best distance so far (octree.cpp:30-33)
+                    const V3 lo = mk(R.v0x, R.v0y, R.v0z), hi = mk(R.e1x, R.e1y, R.e1z);
+                    const double bt1 = run_bt1[wave0 + o];
+                    double r0, r1;
+                    const bool h = fast ? hit_box_fast(lo, hi, e, d, mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z), bt0, bt1, r0, r1)
+                                        : hit_box(lo, hi, e, d, bt0, bt1, r0, r1);
+                    if (h) { tt = r0 - R.e2x / len(d); hit = tt <= tempt; }
+                    id = R.id & ~LEAF_VOXEL;
+                } else {
+                    hit = tri_hit(R, e, d, bt0, tempt, tt);
+                }
+#if RT_STEP_STATS == 5
+                c.rays += 1;                             // records that reached the fp64 test
+#endif
+            }
+            // LDS operations of one wave are carried out in the order they are issued, so each stage
+            // below sees the stage before it; the wave barriers only keep the compiler from mixing them
+            const unsigned long long key = ordered_key(tt);
+#if RT_STEP_STATS == 8
+            if (__builtin_amdgcn_readfirstlane((int)(key != 0ull)) >= 0 && lane == 0) c.prim += (uint32_t)((clock64() - tp0) >> 4);
+#endif
+            __builtin_amdgcn_wave_barrier();
+            if (hit) atomicMin(&L.okey[o], key);
+            __builtin_amdgcn_wave_barrier();
+            const bool best = hit && L.okey[o] == key;
+            if (best) atomicMax(&L.owin[o], tested + lane + 1u);
+            __builtin_amdgcn_wave_barrier();
+            if (best && L.owin[o] == tested + lane + 1u) L.oid[o] = id;
+            __builtin_amdgcn_wave_barrier();
+            if (owner) {
+                const unsigned long long k = L.okey[lane];
+                if (k != ~0ull) {
+                    const double t = ordered_value(k);
+                    if (t <= T.tempt) { T.tempt = t; T.bprim = L.oid[lane]; }      // octree.cpp:30-33
+                }
+            }
+            tested += n;
+#if RT_STEP_STATS == 7
+            if (lane == 0) { c.leaf += 1; c.prim += n; }    // fp64 passes and the candidates they test
+#endif
+        }
+        RT_TICK8(leaf)
+    };
+
+    for (;;) {
+        // ---- step 1: the next job.  An owner with at least a whole chunk of records left takes the
+        // wave for itself (whole chunks of its run need no table: segment s of chunk ch starts at
+        // base + ch * chunk + s * RT_SEG); what is left after that, of all owners, goes through
+        // the segment table.
+        constexpr uint32_t CHUNK_RECS = 64u * RT_LANE_RECS;
+        const uint32_t left = owner ? T.kend - kcur : 0u;
+        const unsigned long long big = __ballot(left >= CHUNK_RECS);
+        bool solo = false;
+        uint32_t solo_o = 0, solo_base = 0, total = 0, nchunk = 0;
+        if (big != 0ull) {
+            solo = true;
+            solo_o = (uint32_t)__ffsll((long long)big) - 1u;
+            solo_base = (uint32_t)__builtin_amdgcn_readlane((int)kcur, (int)solo_o);
+            nchunk = ((uint32_t)__builtin_amdgcn_readlane((int)T.kend, (int)solo_o) - solo_base) / CHUNK_RECS;
+            total = nchunk * SEGS_PER_CHUNK;
+            if (lane == solo_o) kcur += nchunk * CHUNK_RECS;
+        } else {
+            uint32_t nseg = (left + (RT_SEG - 1u)) / RT_SEG;
+            if (nseg > (uint32_t)RT_SEG_ROUND_MAX) nseg = RT_SEG_ROUND_MAX;
+            const unsigned long long b0 = __ballot(nseg & 1u), b1 = __ballot(nseg & 2u), b2 = __ballot(nseg & 4u), b3 = __ballot(nseg & 8u);
+            uint32_t first = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt) + 8u * (uint32_t)__popcll(b3 & lt);
+            total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
+            if (total == 0u) break;
+            RT_TICK9(rays)
+            if (total > (uint32_t)RT_SEG_CAP) total = RT_SEG_CAP;                  // the rest waits for the next round
+            if (first > total) first = total;
+            if (nseg > total - first) nseg = total - first;
+#pragma unroll 1
+            for (uint32_t j = 0; j < (uint32_t)RT_SEG_ROUND_MAX; j++) {
+                if (!__any(j < nseg)) break;
+                if (j < nseg) {
+                    const uint32_t r0 = kcur + j * RT_SEG, cnt = T.kend - r0 < (uint32_t)RT_SEG ? T.kend - r0 : (uint32_t)RT_SEG;
+                    L.seg[first + j] = (unsigned long long)r0 | ((unsigned long long)lane << 32) | ((unsigned long long)cnt << 40);
+                }
+            }
+            if (nseg) { const uint32_t adv = nseg * RT_SEG; kcur = T.kend - kcur < adv ? T.kend : kcur + adv; }
+            nchunk = (total + SEGS_PER_CHUNK - 1u) / SEGS_PER_CHUNK;
+            RT_TICK9(inner)
+        }
+        // ---- step 2: pre-test chunk by chunk.  A lane takes RT_LANE_RECS consecutive records of its
+        // segment (one 16-byte load brings their spheres, one LDS read the owner's ray).  A chunk's
+        // segment entry is read from LDS three chunks and its spheres are requested two chunks ahead
+        // of their use, unconditionally (past the last segment: entry 0 with no records), so that
+        // the wait in front of a chunk's tests leaves the younger loads in flight.  Nothing else is
+        // loaded inside the loop: when the candidate ring cannot take a chunk's candidates the loop
+        // is left, the ring emptied by an fp64 pass, and the loop entered again.
+        RT_TICK8(rays)
+        auto entry = [&](uint32_t ch) -> unsigned long long {
+            const uint32_t sidx = ch * SEGS_PER_CHUNK + sseg;
+            if (solo) {
+                const uint32_t r0 = sidx < total ? solo_base + sidx * RT_SEG : 0u;
+                return (unsigned long long)r0 | ((unsigned long long)solo_o << 32) | ((unsigned long long)(sidx < total ? RT_SEG : 0) << 40);
+            }
+            const unsigned long long v = L.seg[sidx < total ? sidx : 0u];
+            return sidx < total ? v : (v & 0xFF00000000ull);                 // no records
+        };
+        auto spheres = [&](unsigned long long e) -> uint4 {
+            uint4 v;
+            __builtin_memcpy(&v, S.leaf_sph + ((uint32_t)e + sub), 16);       // aligned to a sphere's size only
+            return v;
+        };
+        // Candidates in list order: lane by lane, a lane's records in order.  Of a chunk's candidates
+        // those at places [from, from + take) are appended (all of them, unless the chunk has more
+        // than the ring holds).
+        auto append = [&](const unsigned long long (&m)[RT_LANE_RECS], unsigned long long e0, uint32_t from, uint32_t take) {
+            uint32_t before = 0, mine = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < RT_PRE * RT_SPH_WORDS; i += 4) {
-        uint4 v;
-        __builtin_memcpy(&v, P + i, 16);                 // aligned to the sphere's size only
-        out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+            for (int r = 0; r < RT_LANE_RECS; r++) {
+                before += (uint32_t)__popcll(m[r] & lt);
+                mine |= (uint32_t)((m[r] >> lane) & 1ull) << r;
+            }
+            uint32_t place = before;
+#pragma unroll
+            for (int r = 0; r < RT_LANE_RECS; r++) {
+                if (mine & (1u << r)) {
+                    if (place - from < take) {
+                        const uint32_t slot = (produced + place - from) & (RT_CAND_CAP - 1u);
+                        L.crec[slot] = (uint32_t)e0 + sub + (uint32_t)r; L.cown[slot] = (uint8_t)((uint32_t)(e0 >> 32) & 0xFFu);
+                    }
+                    place++;
+                }
+            }
+        };
+        uint32_t ch = 0;
+        while (ch < nchunk) {
+            // the chunk in hand, and the next one: its entry has been read, its spheres are requested
+            // at the top of the iteration before its own (only while there is a next chunk: a load
+            // that nobody waits for would hold up whoever reuses its register)
+            unsigned long long e0 = entry(ch), e1 = entry(ch + 1u), held_m[RT_LANE_RECS], held_e = 0ull;
+            uint4 sp0 = spheres(e0), sp1 = sp0;
+            bool held = false;
+            uint32_t held_n = 0;
+            for (; ch < nchunk; ch++) {
+                if (ch + 1u < nchunk) sp1 = spheres(e1);
+                const unsigned long long e2 = entry(ch + 2u);
+                const uint32_t o = (uint32_t)(e0 >> 32) & 0xFFu, cnt = (uint32_t)(e0 >> 40);
+                const float4 a_ = rayf[0][wave0 + o], b_ = rayf[1][wave0 + o];
+                RayF rf;
+                rf.ux = a_.x; rf.uy = a_.y; rf.uz = a_.z; rf.nu = a_.w; rf.vx = b_.x; rf.vy = b_.y; rf.vz = b_.z; rf.nv = b_.w;
+                const uint32_t w[RT_LANE_RECS] = { sp0.x, sp0.y, sp0.z, sp0.w };
+                unsigned long long m[RT_LANE_RECS];
+                uint32_t np = 0;
+#pragma unroll
+                for (int r = 0; r < RT_LANE_RECS; r++) {
+                    SphQ q; q.w[0] = w[r];
+                    const bool in_seg = sub + (uint32_t)r < cnt, near = sph_pass(q, rf);
+                    m[r] = __ballot(in_seg & near);
+                    np += (uint32_t)__popcll(m[r]);
+                }
+#if RT_STEP_STATS == 7
+                if (lane == 0) c.inner += 1;                    // chunks
+#endif
+                if (produced - tested + np > (uint32_t)RT_CAND_CAP) {
+                    held = true; held_e = e0; held_n = np;
+#pragma unroll
+                    for (int r = 0; r < RT_LANE_RECS; r++) held_m[r] = m[r];
+                    ch++;
+                    break;
+                }
+                append(m, e0, 0u, np);
+                produced += np;
+                e0 = e1; e1 = e2; sp0 = sp1;
+            }
+            if (held) {
+                // an fp64 pass empties the ring; a chunk with more candidates than the ring holds goes in pieces
+                for (uint32_t from = 0; from < held_n; from += RT_CAND_CAP) {
+                    test_all();
+                    const uint32_t take = held_n - from < (uint32_t)RT_CAND_CAP ? held_n - from : (uint32_t)RT_CAND_CAP;
+                    append(held_m, held_e, from, take);
+                    produced += take;
+                }
+            }
+        }
+    }
+    RT_TICK9(leaf)
+    test_all();
+    RT_TICK8(rays)
+    RT_TICK9(prim)
+    if (owner) {
+#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9
+        c.prim += T.kend - T.k;
+#endif
+        bool improved = false;
+        if (T.bprim != RT_MISS && T.tempt < T.mint) { T.mint = T.tempt; T.minprim = T.bprim; improved = true; }   // octree.cpp:320-325
+        mode = (T.leaf && improved) ? TM_OBJ : TM_POP;                                                          // octree.cpp:326-329
     }
 }
-// A lane that has just opened a run loads the spheres of its first records.
-__device__ __forceinline__ void run_open(const DevScene &S, TravState &T, SphQ (&Q)[RT_PRE])
-{
-    sph_fetch(S, T.k, Q);
-    T.pend = 0; T.cand = RT_MISS;
-}
-// A voxel of an implicit surface (record with LEAF_VOXEL in its id: v0 / e1 = lower / upper
-// corner, e2x = length of the diagonal).  BoxNode::calHit, Surface.cpp:43-59: the slab test runs
-// on the node's whole window [bt0, bt1], the hit is the entry point moved back along the ray by the
-// diagonal, and OctreeNode::hit keeps it if t <= tempt (octree.cpp:30-33).
-__device__ __forceinline__ void voxel_test(const TriReg &tr, TravState &T, double bt1)
-{
-    const V3 lo = mk(tr.v0x, tr.v0y, tr.v0z), hi = mk(tr.e1x, tr.e1y, tr.e1z);
-    double r0, r1;
-    const bool h = T.fast ? hit_box_fast(lo, hi, T.e, T.d, T.r, T.bt0, bt1, r0, r1) : hit_box(lo, hi, T.e, T.d, T.bt0, bt1, r0, r1);
-    if (h) {
-        const double tt = r0 - tr.e2x / len(T.d);
-        if (tt <= T.tempt) { T.tempt = tt; T.bprim = tr.id & ~LEAF_VOXEL; }
-    }
-}
+// OctreeNode::hit for a one-leaf mesh inside the object sweep (every lane walks the same list)
 __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 {
     double tt;
@@ -554,14 +831,13 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
     __shared__ double run_bt1[BLOCK];        // upper end of the window of the lane's current primitive run
-    // the lane's ray for the sphere pre-test (see RayF), read back by every triangle step: direction
+    // the lane's ray for the sphere pre-test (see RayF), read back by the triangle phase: u and v
     // and 1/|d|^2 are formed whenever T.d changes, the entry point and its slack when a run opens
     // (node_step)
     __shared__ float4 rayf[2][BLOCK];
-#define RT_RAYF_PUT() { const RayF q_ = ray_single(T.e, T.d); rayf[0][tid] = make_float4(q_.ex, q_.ey, q_.ez, q_.inv_dd); rayf[1][tid] = make_float4(q_.dx, q_.dy, q_.dz, q_.slack); }
+#define RT_RAYF_PUT() { const RayF q_ = ray_single(T.d); rayf[0][tid] = make_float4(q_.ux, q_.uy, q_.uz, 0.0f); rayf[1][tid] = make_float4(q_.vx, q_.vy, q_.vz, 0.0f); }
+    __shared__ CoopLds coop[BLOCK / 64];      // the wave's candidate list of the cooperative triangle phase
     TravState T = {};
-    TriReg R = {};
-    SphQ Q[RT_PRE] = {};
     int mode = TM_FETCH;
     // rays are handed to a wave in batches of 64 .. batch_max: a quarter of an even share of what is left
     const uint32_t nwaves = gridDim.x * (BLOCK / 64);
@@ -775,67 +1051,21 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 const bool in = mode == TM_NODE;
                 if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
                 else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
-                if (in && mode == TM_TRI) run_open(S, T, Q);
                 RT_TICK(inner)
                 continue;
             }
-            // ------------------------------------------------------------ triangle steps
-            for (;;) {
+            // ------------------------------------------------------------ triangle phase
 #if RT_STEP_STATS == 1
-                c.prim += 1;
+            c.prim += 1;
+#elif RT_STEP_STATS == 7
+            if (lane == 0) c.rays += 1;                         // triangle phases
 #elif RT_STEP_STATS == 3
-                {   // triangle steps (rays), and the lanes in each state at those steps
-                    const uint32_t sT = (uint32_t)__popcll(__ballot(mode == TM_TRI)), sN = (uint32_t)__popcll(__ballot(mode == TM_NODE || mode == TM_POP));
-                    const uint32_t sO = (uint32_t)__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH));
-                    if (lane == 0) { c.rays += 1; c.inner += sT; c.leaf += sN; c.prim += sO; }
-                }
-#endif
-                if (mode == TM_TRI) {
-                    // 1. the fp64 test of the record requested in the previous step
-                    if (T.cand != RT_MISS) {
-                        if (R.id & LEAF_VOXEL) voxel_test(R, T, run_bt1[tid]); else tri_test(R, T);
-#if RT_STEP_STATS == 5
-                        c.rays += 1;                                 // records that reached the fp64 test
-#endif
-                        T.cand = RT_MISS;
-                    }
-                    // 2. pre-test the next records; the ones that pass queue up behind those that still
-                    //    wait for their fp64 test (bit j of pend = record pbase + j), as long as the
-                    //    32-bit queue has room
-                    if (T.pend == 0u) T.pbase = T.k;
-                    if (T.k < T.kend && T.k - T.pbase + (uint32_t)RT_PRE <= 32u) {
-                        RayF rf;
-                        { const float4 a_ = rayf[0][tid], b_ = rayf[1][tid]; rf.ex = a_.x; rf.ey = a_.y; rf.ez = a_.z; rf.inv_dd = a_.w; rf.dx = b_.x; rf.dy = b_.y; rf.dz = b_.z; rf.slack = b_.w; }
-                        const uint32_t left = T.kend - T.k, take = left < (uint32_t)RT_PRE ? left : (uint32_t)RT_PRE;
-                        uint32_t m = 0;
-#pragma unroll
-                        for (uint32_t i = 0; i < RT_PRE; i++) m |= sph_pass(Q[i], rf) ? 1u << i : 0u;
-                        T.pend |= (m & ((1u << take) - 1u)) << (T.k - T.pbase);
-                        T.k += take;
-#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6
-                        c.prim += take;
-#endif
-                        // the spheres of the records after these
-                        sph_fetch(S, T.k, Q);
-                    }
-                    // 3. request the first waiting record (candidates are tested in list order, so
-                    //    "the last equal hit wins", octree.cpp:31, is kept)
-                    if (T.pend != 0u) {
-                        const uint32_t j = (uint32_t)__ffs((int)T.pend) - 1u;
-                        T.pend &= T.pend - 1u;
-                        T.cand = T.pbase + j;
-                        R = tri_load(S.leaf_tris + T.cand);
-                    } else if (T.k >= T.kend) {
-                        bool improved = false;
-                        if (T.bprim != RT_MISS && T.tempt < T.mint) { T.mint = T.tempt; T.minprim = T.bprim; improved = true; }   // octree.cpp:320-325
-                        mode = (T.leaf && improved) ? TM_OBJ : TM_POP;         // octree.cpp:326-329
-                    }
-                }
-                const int nT = __popcll(__ballot(mode == TM_TRI)) * RT_WT;
-                if (nT == 0) break;
-                if (__popcll(__ballot(mode == TM_NODE || mode == TM_POP)) * RT_WN >= nT) break;
-                if (__popcll(__ballot(mode == TM_OBJ || mode == TM_FETCH)) * RT_OBJ_WEIGHT(S) >= nT) break;
+            {   // triangle phases, and the lanes in each state when they start
+                const uint32_t sN = (uint32_t)__popcll(mN), sO = (uint32_t)__popcll(mO);
+                if (lane == 0) { c.rays += 1; c.inner += (uint32_t)__popcll(mT); c.leaf += sN; c.prim += sO; }
             }
+#endif
+            tri_phase<BLOCK>(S, T, mode, run_bt1, rayf, coop[tid >> 6], c);
             RT_TICK(leaf)
         }
         if (finished) break;
