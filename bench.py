@@ -38,7 +38,8 @@ from raytracer_amd.parallel import dist_env, sample_slice  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (operations/s, a fused multiply-add = 1:
                                # the path is built without contraction, so an operation is one flop)
-RAY_RECORD_BYTES = 96.0        # a pending ray: 12 eight-byte fields
+RAY_RECORD_BYTES = 88.0        # a pending bounce ray: 11 eight-byte fields
+SHADOW_RECORD_BYTES = 84.0     # a pending shadow ray: 10 eight-byte fields and the pixel index
 SHADE_READ_BYTES = 40.0        # what shading reads of every ray: meta word, hit id, throughput
 
 
@@ -46,7 +47,8 @@ def shade_bytes(flow):
     """Bytes the shading kernel has to move for the rays it handled (a lower bound: the 64 bytes
     more that a shaded hit reads and the 24 bytes a contributing ray adds to its pixel are left
     out): the fields every ray is read for, and one record written per follow-up ray."""
-    return SHADE_READ_BYTES * flow["shaded_in"] + RAY_RECORD_BYTES * (flow["appended_class0"] + flow["appended_class1"])
+    return (SHADE_READ_BYTES * flow["shaded_in"] + RAY_RECORD_BYTES * (flow["bounce_class0"] + flow["bounce_class1"])
+            + SHADOW_RECORD_BYTES * (flow["shadow_class0"] + flow["shadow_class1"]))
 
 
 def algorithmic_lane_ops(cnt):
@@ -94,6 +96,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: samples per GPU fixed (default); strong: the frame fixed (bunny 256 spp, atrium 1024 spp), "
                          "its samples dealt to the ranks")
+    ap.add_argument("--workspace-gb", type=float, default=0.0,
+                    help="upper bound on the pending-ray stacks in GB (0 = the library's default: 16 Mi rays a round, at most a "
+                         "quarter of the free device memory); RT_WAVEFRONT_RAYS in the environment sets the rays per round")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -115,6 +120,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # rays per round: the library's default is 16 Mi; the benchmark has the card to itself and takes 32 Mi
+    # (+3 % rays/s for twice the stack memory, reported as workspace_gb)
+    os.environ.setdefault("RT_WAVEFRONT_RAYS", str(32 << 20))
     seed = 1243                                 # the reference's srand value (scene.cpp:22)
     if a.workload == "atrium":
         W, H = (1920, 1080) if a.size == 1024 else (a.size * 16 // 9, a.size)
@@ -134,6 +142,8 @@ def main():
     ntris = sum(len(x) for x in desc.meshes)
     t0 = time.time()
     sc = hip.HipScene(desc)
+    if a.workspace_gb > 0:
+        sc.set_workspace_limit(int(a.workspace_gb * 1e9))
     upload_s = time.time() - t0
     c = hip.camera_init(**cam)
     b, e = sample_slice(rank, world, n * m)
@@ -210,7 +220,14 @@ def main():
             except Exception:
                 pmc = {}
         ptrace, pshade = pmc.get("trace", {}), pmc.get("shade", {})
-        traffic = ptrace.get("hbm_bytes_per_launch")
+
+        def per_launch(fig, launches_per_step):
+            """HBM bytes per launch: the profiled step's total for the kernel (the same frame) over this run's launches per step."""
+            if "fetch_bytes_total_corrected" not in fig:
+                return None
+            return (fig["fetch_bytes_total_corrected"] + fig["write_bytes_total"]) / max(launches_per_step, 1.0)
+
+        traffic = per_launch(ptrace, prof["trace_launches"] / steps)
         src = f"replayed from profiles/pmc_{a.workload}.json (rocprofv3 --pmc passes of this command, {pmc.get('collected', 'n/a')})" if pmc else None
         shade_launches = max(prof["shade_launches"], 1.0)
         shade_avg_ms = prof["shade_ms"] / shade_launches
@@ -236,6 +253,7 @@ def main():
             "mpaths_per_s": paths_per_step * steps / dt / 1e6,
             "rays_per_path": rays_per_step / paths_per_step,
             "upload_s": upload_s,
+            "workspace_gb": sc.workspace_bytes() / 1e9,
             "roofline": {"kernel": "rt::k_trace (octree closest hit)", "bound": "valu-fp64",
                          "achieved": achieved_ops / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": achieved_ops / VALU_FP64_PEAK, "traffic": traffic, "traffic_source": src,
@@ -245,7 +263,7 @@ def main():
                          "share_of_step_time": prof["trace_ms"] * 1e-3 / dt},
             "roofline_shade": {"kernel": "rt::k_shade (shading + ray append)", "bound": "hbm",
                                "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
-                               "traffic": pshade.get("hbm_bytes_per_launch"), "traffic_source": src if pshade else None,
+                               "traffic": per_launch(pshade, prof["shade_launches"] / steps), "traffic_source": src if pshade else None,
                                "launches": shade_launches, "avg_launch_ms": shade_avg_ms, "algorithmic_bytes_per_launch": shade_b,
                                "share_of_step_time": prof["shade_ms"] * 1e-3 / dt},
             "stage_ms_per_step": {"trace": prof["trace_ms"] / steps, "shade": prof["shade_ms"] / steps,

@@ -259,9 +259,19 @@ int rt_scene_set_profiling(rt_scene *scene, int enable);
 int rt_scene_get_profile(rt_scene *scene, double out[6], int reset);
 /* Rays that went through the path-tracing pipeline since the last reset, counted by the host
  * driver (always, profiling enabled or not): out = {first rays generated, rays traced and handed
- * to shading, follow-up rays appended that end inside object phases, follow-up rays appended that
- * reach an octree with inner nodes}.  No counterpart in the reference. */
-int rt_scene_get_ray_flow(rt_scene *scene, double out[4], int reset);
+ * to shading, bounce rays appended that end inside object phases, bounce rays appended that reach
+ * an octree with inner nodes, shadow rays appended of the one kind, of the other}.  No counterpart
+ * in the reference. */
+int rt_scene_get_ray_flow(rt_scene *scene, double out[6], int reset);
+/* The device memory rt_render / rt_ray_color may take for their pending-ray stacks (one allocation
+ * per scene handle, made by the first call that needs it, grown by later ones, freed by
+ * rt_scene_destroy).  By default a call sizes its rounds to 16 Mi rays (RT_WAVEFRONT_RAYS in the
+ * environment overrides) and never takes more than a quarter of the device memory that is free;
+ * with a limit set, rounds shrink until the stacks fit `bytes` (0 = back to the default).  Smaller
+ * rounds change speed only, never results.  rt_scene_workspace_bytes: what the handle holds now.
+ * No counterpart in the reference. */
+int rt_scene_set_workspace_limit(rt_scene *scene, uint64_t bytes);
+int64_t rt_scene_workspace_bytes(const rt_scene *scene);
 
 /* colorArray_ -> bytes: average, Vec4::regularize (types.h:167-177), int(c*255) stored B,G,R
  * (scene.cpp:183-185).  bgr = height x width x 3 bytes, bottom row first. */
@@ -274,6 +284,51 @@ int rt_resolve_bgr8_host(const double *radiance_sum, int width, int height, int 
 enum { RT_TONE_NONE = 0, RT_TONE_SIGMOID = 1, RT_TONE_SQRT = 2 };
 int rt_resolve_tone_bgr8(const double *radiance_sum, int width, int height, int spp, int tone, uint8_t *bgr, void *stream);
 int rt_resolve_tone_bgr8_host(const double *radiance_sum, int width, int height, int spp, int tone, uint8_t *bgr);
+
+/* ---- more than one GPU.  The reference's only parallelism is Scene::runParallelly(threadNum)
+ * (scene.cpp:141-172: an OpenMP pixel queue over per-thread clones of the scene); here the sample
+ * indices of every pixel are dealt to devices, each device renders its slice into a full-frame
+ * buffer of un-normalised sums (rt_render), the buffers are added onto the root and the root
+ * resolves the frame -- the clamp comes after the average (scene.cpp:112-113), so the sums must
+ * meet unclamped.
+ *
+ * rt_comm: the RCCL communicator of that one exchange.  rt_comm_create: all members in this
+ * process (ncclCommInitAll over `devices`, each listed once; member i = rank i).  For one process
+ * per GPU: rank 0 calls rt_comm_unique_id, hands the 128 bytes to the others by any means, and
+ * every rank calls rt_comm_init_rank (a communicator with one local member, member 0).
+ * rt_reduce_and_resolve (every member must call it, each from its own thread or process):
+ * radiance_sum (device, width x height x 3) is summed onto rank 0 in place with one reduce on
+ * `stream`; on rank 0, if bgr (device) is given, the frame is then resolved as by
+ * rt_resolve_tone_bgr8 with the frame's total sample count `spp`.  RCCL is loaded when first
+ * needed; without it these calls fail with an error. */
+typedef struct rt_comm rt_comm;
+int rt_comm_create(int ndev, const int *devices, rt_comm **out);
+int rt_comm_unique_id(uint8_t id[128]);
+int rt_comm_init_rank(const uint8_t id[128], int nranks, int rank, int device, rt_comm **out);
+int rt_comm_size(const rt_comm *comm);
+int rt_comm_destroy(rt_comm *comm);
+int rt_reduce_and_resolve(rt_comm *comm, int member, double *radiance_sum, int width, int height, int spp,
+                          int tone, uint8_t *bgr, void *stream);
+
+/* Scene::runParallelly for one process that drives several devices: a scene handle per device
+ * (the reference clones its scene per worker, scene.cpp:150) and, per frame, one host thread per
+ * device that renders a contiguous, balanced slice of [sample_begin, sample_end) and joins the
+ * reduce.  reduce_mode RT_REDUCE_RCCL: rt_reduce_and_resolve over a communicator of the devices
+ * (each listed once).  RT_REDUCE_HOST: the buffers are added in host memory in member order and the
+ * sum resolved on member 0's device -- slower, needs no RCCL, and lets one device appear several
+ * times (several members sharing a card, e.g. to rehearse the partition on a one-GPU machine).
+ * rt_multi_render: tone as in rt_resolve_tone_bgr8; radiance_sum_host (width x height x 3 sums of
+ * the whole range) and bgr_host (width x height x 3 bytes) are host buffers, each nullable;
+ * counters (nullable, host, 4 x u64) += the members' work counters.  rt_multi_scene: member i's
+ * handle, e.g. for rt_scene_set_light between frames (every member must be given the same changes). */
+enum { RT_REDUCE_RCCL = 0, RT_REDUCE_HOST = 1 };
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc *desc, const int *devices, int ndev, int reduce_mode, rt_multi **out);
+int rt_multi_size(const rt_multi *multi);
+rt_scene *rt_multi_scene(rt_multi *multi, int member);
+int rt_multi_render(rt_multi *multi, const rt_camera *cam, const rt_render_params *params, int tone,
+                    double *radiance_sum_host, uint8_t *bgr_host, uint64_t counters[4]);
+int rt_multi_destroy(rt_multi *multi);
 
 /* Snapshot (bmpgenerator.cpp:3-45) with fixed-width header fields: 14 + 40 byte headers,
  * 24 bpp, bottom-up rows.  Rows are padded to a multiple of four bytes as the format requires; the

@@ -4,8 +4,10 @@
 // them to a Scene, call runParallelly(), read pixels with queryColor() or saveToBpm().
 //
 // What differs from the reference, on purpose:
-//   * Scene::runParallelly(threadNum) renders on the GPU (threadNum is accepted and ignored);
-//     there is no CPU rendering path behind this header.
+//   * Scene::runParallelly(threadNum) renders on GPUs: the reference's worker count becomes the
+//     number of devices to use at most (one host thread, one copy of the scene and one slice of
+//     the sample indices per device, the devices' sums added with one RCCL reduce); 0 or 1, or a
+//     machine with one GPU, means one device.  There is no CPU rendering path behind this header.
 //   * Mesh is new: a Drawable holding triangles in an Octree (the role HeartShape /
 //     ImplicitSurface play in the reference, Surface.h:131-174).
 //   * the sampler constants that are private members without setters in the reference
@@ -316,7 +318,7 @@ private:
 class Scene {                                                                // scene.h:8-56
 public:
     Scene() = default;
-    ~Scene() { if (handle_) rt_scene_destroy(handle_); }
+    ~Scene() { release(); }
     Scene(const Scene &) = delete;
     Scene &operator=(const Scene &) = delete;
 
@@ -349,27 +351,32 @@ public:
         if (usesPerlin()) {
             ensurePerlin();
             rt_perlin_time_changed(&perlinClock_, time_, time, 256, perlinG_.data());
-            if (handle_ && !dirty_ && rt_scene_set_perlin(handle_, perlinP_.data(), perlinG_.data(), 256, nullptr)) return -1;
+            if (!dirty_) for (rt_scene *h : handles()) if (rt_scene_set_perlin(h, perlinP_.data(), perlinG_.data(), 256, nullptr)) return -1;
         }
         time_ = time;
         if (camera_) camera_->setTime(time);
         for (size_t i = 0; i < lights_.size(); i++)
-            if (lights_[i]->setTime(time) && handle_ && !dirty_)
-                if (rt_scene_set_light(handle_, i, &lights_[i]->record(), nullptr)) return -1;
+            if (lights_[i]->setTime(time) && !dirty_)
+                for (rt_scene *h : handles()) if (rt_scene_set_light(h, i, &lights_[i]->record(), nullptr)) return -1;
         return 0;
     }
 
-    // Scene::run() / runParallelly(threadNum), scene.cpp:95-172: the whole frame, on the GPU.
-    int run() { return runParallelly(0); }
-    int runParallelly(int /*threadNum*/)
+    // Scene::run() / runParallelly(threadNum), scene.cpp:95-172: the whole frame, on the GPU(s).
+    int run() { return runParallelly(1); }
+    int runParallelly(int threadNum)
     {
         if (px_ <= 0 || py_ <= 0 || !camera_) return -1;
-        if (upload()) return -1;
+        int ndev = rt_device_count();
+        if (ndev < 1) return -1;
+        if (threadNum < ndev) ndev = threadNum < 1 ? 1 : threadNum;
+        if (upload(ndev)) return -1;
         rt_render_params p{};
         p.width = px_; p.height = py_; p.n = n_; p.m = m_; p.sample_begin = 0; p.sample_end = n_ * m_;
         p.max_jump = maxJump_; p.rus_jump = rusJump_; p.seed = seed_; p.face_forward = faceForward_ ? 1 : 0;
         sum_.assign((size_t)px_ * py_ * 3, 0.0);
-        if (rt_render_host(handle_, &camera_->record(), &p, sum_.data(), rays_)) return -1;
+        if (multi_) {
+            if (rt_multi_render(multi_, &camera_->record(), &p, tone_, sum_.data(), nullptr, rays_)) return -1;
+        } else if (rt_render_host(handle_, &camera_->record(), &p, sum_.data(), rays_)) return -1;
         run_ = true;
         return 0;
     }
@@ -398,10 +405,23 @@ public:
     uint64_t raysTraced() const { return rays_[0]; }
 
 private:
-    int upload()
+    void release()
     {
-        if (handle_ && !dirty_) return 0;
         if (handle_) { rt_scene_destroy(handle_); handle_ = nullptr; }
+        if (multi_) { rt_multi_destroy(multi_); multi_ = nullptr; }
+    }
+    // the uploaded copies of the scene: one, or one per device
+    std::vector<rt_scene *> handles() const
+    {
+        std::vector<rt_scene *> v;
+        if (handle_) v.push_back(handle_);
+        if (multi_) for (int i = 0; i < rt_multi_size(multi_); i++) v.push_back(rt_multi_scene(multi_, i));
+        return v;
+    }
+    int upload(int ndev)
+    {
+        if (!dirty_ && ((ndev == 1 && handle_) || (ndev > 1 && multi_ && rt_multi_size(multi_) == ndev))) return 0;
+        release();
         std::vector<rt_object> objs; std::vector<rt_material> mats; std::vector<std::vector<double>> meshes; std::vector<rt_light> lights;
         if (node_ && node_->flatten(objs, mats, meshes)) return -1;
         for (const auto &l : lights_) {                                      // light geometry joins the group, scene.cpp:89-91
@@ -421,7 +441,11 @@ private:
         bool perlin = false;
         for (const rt_material &m : mats) perlin = perlin || m.perlin != RT_PERLIN_NONE;
         if (perlin) { ensurePerlin(); d.perlin_p = perlinP_.data(); d.perlin_g = perlinG_.data(); d.perlin_n = 256; }
-        if (rt_scene_create(&d, &handle_)) return -1;
+        if (ndev > 1) {
+            std::vector<int> devices(ndev);
+            for (int i = 0; i < ndev; i++) devices[i] = i;
+            if (rt_multi_create(&d, devices.data(), ndev, RT_REDUCE_RCCL, &multi_)) return -1;
+        } else if (rt_scene_create(&d, &handle_)) return -1;
         dirty_ = false;
         return 0;
     }
@@ -453,7 +477,8 @@ private:
     double implicitMin_ = 0;
     int tone_ = RT_TONE_NONE;
     uint64_t seed_ = 1243;                                                   // scene.cpp:22
-    rt_scene *handle_ = nullptr;
+    rt_scene *handle_ = nullptr;       // one device
+    rt_multi *multi_ = nullptr;        // several devices
     std::vector<double> sum_;
     uint64_t rays_[4] = {0, 0, 0, 0};
 };

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "rt_device.h"
+#include "rt_internal.h"
 #include "rt_kernels.h"
 #include "rt_octree.h"
 
@@ -40,6 +41,8 @@ hipError_t upload(const std::vector<T> &v, void **dptr)
 
 } // namespace
 
+int rt::set_error(const std::string &message, int code) { g_err = message; return code; }
+
 struct rt_scene {
     int device = 0;
     int num_cu = 0;
@@ -51,18 +54,20 @@ struct rt_scene {
     bool has_implicit[2] = {false, false};
     std::vector<rt_material> materials;
     int nlights = 0;
-    int max_push = 1;             // most follow-up rays one shaded hit can append
-    // path-tracing workspace (grown on demand, reused by later calls)
-    RayStack stack[2][2] = {};    // [class][side]
-    void *stack_mem[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    uint32_t *d_ctrl = nullptr;   // [0],[1] rays appended per class by the running kernel; [2] k_trace's ray counter; [3] the closest-hit entry points' ray counter
-    uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0..1]
+    int max_push = 1;             // most radiance (bounce) rays one shaded hit can append
+    int max_shadow = 0;           // most shadow rays one shaded hit can append
+    // path-tracing workspace (grown on demand, reused by later calls): one allocation, carved into the ray stacks
+    void *ws_mem = nullptr;
+    uint64_t ws_bytes = 0;
+    uint64_t ws_limit = 0;        // rt_scene_set_workspace_limit (0 = the default policy)
+    uint32_t *d_ctrl = nullptr;   // [0..3] rays appended per destination by the running kernel; [4] the path tracer's ray hand-out counter; [5] the closest-hit entry points' one
+    uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0..3]
     int failed = 0;               // a render ran out of ray-stack space
     // optional stage timing
     int profiling = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof[6] = {0, 0, 0, 0, 0, 0}; // trace launches, trace ms, shade launches, shade ms, generate launches, rounds
-    double flow[4] = {0, 0, 0, 0};       // first rays generated, rays traced and shaded, follow-up rays appended (class 0, class 1)
+    double flow[6] = {0, 0, 0, 0, 0, 0}; // first rays generated, rays traced and shaded, bounce rays appended (class 0, 1), shadow rays appended (class 0, 1)
 };
 
 extern "C" {
@@ -230,10 +235,10 @@ int rt_scene_destroy(rt_scene *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) if (s->stack_mem[c][k]) (void)hipFree(s->stack_mem[c][k]);
+    if (s->ws_mem) (void)hipFree(s->ws_mem);
     if (s->d_ctrl) (void)hipFree(s->d_ctrl);
     if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
-    for (int k = 0; k < 3; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+    for (int k = 0; k < 5; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     delete s;
     return 0;
 }
@@ -615,9 +620,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         if (m.type & RT_MAT_SPECULAR) s->dev.shade_kinds |= 1;
         if (m.type & RT_MAT_TRANSPARENT) s->dev.shade_kinds |= 2;
     }
-    for (const rt_material &m : mats) {
-        int push = ((m.type & RT_MAT_NORMAL) ? 1 + s->nlights : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 2 : 0);
+    for (const DevObject &q : objs) {                 // over the materials that objects use
+        const rt_material &m = mats[q.material];
+        const int push = ((m.type & RT_MAT_NORMAL) && (m.type & RT_MAT_MONTECARLO) ? 1 : 0) + ((m.type & RT_MAT_SPECULAR) ? 1 : 0) + ((m.type & RT_MAT_TRANSPARENT) ? 2 : 0);
         if (push > s->max_push) s->max_push = push;
+        if ((m.type & RT_MAT_NORMAL) && s->nlights > s->max_shadow) s->max_shadow = s->nlights;
     }
     *out = s;
     return 0;
@@ -657,7 +664,7 @@ int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double
     if (n && (!rays || !prim_id)) return fail("rt_trace_rays: null buffer");
     if (n >= 0xFFFFFFFFull) return fail("rt_trace_rays: batch too large");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 3, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 5, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -667,7 +674,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *
     if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || (uint64_t)w * (uint64_t)h >= 0xFFFF0000ull) return fail("rt_trace_primary: bad image size");
     if (!prim_id) return fail("rt_trace_primary: null buffer");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 3, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 5, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -689,68 +696,89 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
     return (end && *end == 0 && x > 0) ? (uint64_t)x : dflt;
 }
 
-static void free_stacks(rt_scene *s)
+// The device memory one run of the pipeline works in: four radiance stacks of `cap` slots
+// ([class][side]: a class's follow-up rays go to its other side), two shadow stacks of `scap` slots,
+// and the control words (see rt_scene::d_ctrl); `target` = rays per round.  With P = most bounce
+// rays and L = most shadow rays per shaded hit: cap = target (P + 3), scap = target (L + 1) (a
+// shadow stack is emptied as soon as it holds `target` rays, and one round adds at most target L).
+struct WaveSpace {
+    RayStack stack[2][2];
+    ShadowStack sstack[2];
+    uint32_t *d_ctrl;
+    uint64_t cap, scap, target;
+};
+
+static uint64_t round256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
+static uint64_t radiance_stack_bytes(uint64_t cap) { return round256(cap * (RAY_FIELDS + 2) * sizeof(uint64_t)); }
+static uint64_t shadow_stack_bytes(uint64_t scap) { return round256(scap * SH_FIELDS * sizeof(uint64_t)) + round256(scap * sizeof(uint32_t)); }
+static uint64_t workspace_bytes(uint64_t target, uint64_t P, uint64_t L)
 {
+    return 4 * radiance_stack_bytes(target * (P + 3)) + 2 * shadow_stack_bytes(target * (L + 1));
+}
+// Lays the six stacks for `target` rays per round out in memory at `base` (256-byte aligned).
+static void carve_workspace(void *base, uint64_t target, uint64_t P, uint64_t L, WaveSpace &ws)
+{
+    unsigned char *p = (unsigned char *)base;
+    ws.target = target; ws.cap = target * (P + 3); ws.scap = target * (L + 1);
     for (int c = 0; c < 2; c++)
         for (int k = 0; k < 2; k++) {
-            if (s->stack_mem[c][k]) (void)hipFree(s->stack_mem[c][k]);
-            s->stack_mem[c][k] = nullptr;
-            s->stack[c][k] = RayStack{};
+            uint64_t *m = (uint64_t *)p;
+            ws.stack[c][k].f = m;
+            ws.stack[c][k].hit_t = (double *)(m + ws.cap * RAY_FIELDS);
+            ws.stack[c][k].hit_id = m + ws.cap * (RAY_FIELDS + 1);
+            ws.stack[c][k].cap = ws.cap;
+            p += radiance_stack_bytes(ws.cap);
         }
+    for (int c = 0; c < 2; c++) {
+        ws.sstack[c].f = (uint64_t *)p;
+        ws.sstack[c].pix = (uint32_t *)(p + round256(ws.scap * SH_FIELDS * sizeof(uint64_t)));
+        ws.sstack[c].cap = ws.scap;
+        p += shadow_stack_bytes(ws.scap);
+    }
 }
 
-// All four stacks with `cap` slots each, or none: a failed allocation leaves the scene without
-// stacks (every cap 0), never with some of them.
-static int ensure_stacks(rt_scene *s, uint64_t cap, hipStream_t st)
+// One allocation of at least `bytes`, or none: a failed allocation leaves the scene without a workspace.
+static int ensure_workspace(rt_scene *s, uint64_t bytes, hipStream_t st)
 {
-    bool have = true;
-    for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) have = have && s->stack_mem[c][k] && s->stack[c][k].cap >= cap;
-    if (have) return 0;
+    if (s->ws_mem && s->ws_bytes >= bytes) return 0;
     HIP_TRY(hipStreamSynchronize(st));
-    free_stacks(s);
-    const size_t words = (size_t)cap * (RAY_FIELDS + 2);
-    void *mem[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 4; i++) {
-        const hipError_t e = hipMalloc(&mem[i], words * sizeof(uint64_t));
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            for (int j = 0; j < i; j++) (void)hipFree(mem[j]);
-            return fail_hip("hipMalloc (ray stacks)", e);
-        }
-    }
-    for (int c = 0; c < 2; c++)
-        for (int k = 0; k < 2; k++) {
-            s->stack_mem[c][k] = mem[2 * c + k];
-            uint64_t *base = (uint64_t *)mem[2 * c + k];
-            s->stack[c][k].f = base;
-            s->stack[c][k].hit_t = (double *)(base + (size_t)cap * RAY_FIELDS);
-            s->stack[c][k].hit_id = base + (size_t)cap * (RAY_FIELDS + 1);
-            s->stack[c][k].cap = cap;
-        }
+    if (s->ws_mem) { (void)hipFree(s->ws_mem); s->ws_mem = nullptr; s->ws_bytes = 0; }
+    void *mem = nullptr;
+    const hipError_t e = hipMalloc(&mem, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail_hip("hipMalloc (ray stacks)", e); }
+    s->ws_mem = mem; s->ws_bytes = bytes;
     return 0;
 }
 
-// The device memory one run of the pipeline works in: four ray stacks of `cap` slots ([class][side])
-// and the control words (see rt_scene::d_ctrl); `target` = rays per round.
-struct WaveSpace {
-    RayStack stack[2][2];
-    uint32_t *d_ctrl;
-    uint64_t cap, target;
-};
-
 static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_t total_items, hipStream_t st)
 {
-    const uint64_t max_push = (uint64_t)s->max_push, cap = ws.cap, target = ws.target;
+    const uint64_t max_push = (uint64_t)s->max_push, max_shadow = (uint64_t)s->max_shadow, cap = ws.cap, target = ws.target;
     uint32_t *const d_ctrl = ws.d_ctrl;
     s->failed = 0;              // a failure of an earlier call has been reported by rt_scene_check or by that call's own status
-    uint64_t count[2][2] = {{0, 0}, {0, 0}};      // [class][side]
+    uint64_t count[2][2] = {{0, 0}, {0, 0}};      // radiance rays pending, [class][side]
+    uint64_t scount[2] = {0, 0};                  // shadow rays pending, [class]
     int cur[2] = {0, 0};                          // side that is the class's source
     uint64_t issued = 0;
-    // how many rays each class received from the kernel that has just been enqueued
-    auto read_counts = [&](uint64_t &n0, uint64_t &n1) -> int {
-        HIP_TRY(hipMemcpyAsync(s->h_ctrl, d_ctrl, 8, hipMemcpyDeviceToHost, st));
+    // how many rays each destination received from the kernel that has just been enqueued
+    auto read_counts = [&](uint64_t n[4]) -> int {
+        HIP_TRY(hipMemcpyAsync(s->h_ctrl, d_ctrl, 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        n0 = s->h_ctrl[0]; n1 = s->h_ctrl[1];
+        for (int k = 0; k < 4; k++) n[k] = s->h_ctrl[k];
+        return 0;
+    };
+    // the shadow tests of everything on a shadow stack (nothing is appended by them, so nothing is read back)
+    auto drain = [&](int cls) -> int {
+        if (!scount[cls]) return 0;
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[3], st));
+        HIP_TRY(launch_trace_shadow(s->dev, s->num_cu, d_ctrl + 4, A, ws.sstack[cls], 0, (uint32_t)scount[cls], cls, st));
+        if (s->profiling) {
+            float a = 0;
+            HIP_TRY(hipEventRecord(s->ev[4], st));
+            HIP_TRY(hipEventSynchronize(s->ev[4]));
+            HIP_TRY(hipEventElapsedTime(&a, s->ev[3], s->ev[4]));
+            s->prof[0] += 1; s->prof[1] += a;
+        }
+        scount[cls] = 0;
         return 0;
     };
     for (;;) {
@@ -763,13 +791,13 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
             for (int c = 0; c < 2; c++) if (m > cap - count[c][cur[c]]) m = cap - count[c][cur[c]];
             if (m) {
                 RayDest D;
-                for (int c = 0; c < 2; c++) { D.q[c] = ws.stack[c][cur[c]]; D.base[c] = count[c][cur[c]]; }
+                for (int c = 0; c < 2; c++) { D.q[c] = ws.stack[c][cur[c]]; D.base[c] = count[c][cur[c]]; D.sq[c] = ws.sstack[c]; D.sbase[c] = scount[c]; }
                 D.count = d_ctrl;
-                HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));
+                HIP_TRY(hipMemsetAsync(d_ctrl, 0, 16, st));
                 HIP_TRY(launch_generate(s->dev, A, D, issued, (uint32_t)m, st));
-                uint64_t n0, n1;
-                if (int rc = read_counts(n0, n1)) return rc;
-                count[0][cur[0]] += n0; count[1][cur[1]] += n1;
+                uint64_t n[4];
+                if (int rc = read_counts(n)) return rc;
+                count[0][cur[0]] += n[0]; count[1][cur[1]] += n[1];
                 s->prof[4] += 1;
                 s->flow[0] += (double)m;
                 issued += m;
@@ -777,27 +805,30 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
         }
         const int X = count[0][cur[0]] > count[1][cur[1]] ? 0 : 1, Y = X ^ 1;
         if (count[X][cur[X]] == 0) {
-            if (issued < total_items) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+            if (issued < total_items) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise the workspace limit)"); }
             break;
         }
         uint64_t c = count[X][cur[X]] < target ? count[X][cur[X]] : target;
         const uint64_t roomX = (cap - count[X][cur[X] ^ 1]) / max_push, roomY = (cap - count[Y][cur[Y]]) / max_push;
         if (c > roomX) c = roomX;
         if (c > roomY) c = roomY;
-        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise RT_WAVEFRONT_RAYS)"); }
+        if (c == 0) { s->failed = 1; return fail("path tracing ran out of ray-stack space (raise the workspace limit)"); }
+        // room for the shadow rays of this round
+        for (int k = 0; k < 2; k++) if (scount[k] + c * max_shadow > ws.scap) if (int rc = drain(k)) return rc;
         const uint64_t base = count[X][cur[X]] - c;
         RayDest D;
         D.q[X] = ws.stack[X][cur[X] ^ 1]; D.base[X] = count[X][cur[X] ^ 1];
         D.q[Y] = ws.stack[Y][cur[Y]];     D.base[Y] = count[Y][cur[Y]];
+        for (int k = 0; k < 2; k++) { D.sq[k] = ws.sstack[k]; D.sbase[k] = scount[k]; }
         D.count = d_ctrl;
-        HIP_TRY(hipMemsetAsync(d_ctrl, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(d_ctrl, 0, 16, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
-        HIP_TRY(launch_trace(s->dev, s->num_cu, d_ctrl + 2, A, ws.stack[X][cur[X]], base, (uint32_t)c, X, st));
+        HIP_TRY(launch_trace(s->dev, s->num_cu, d_ctrl + 4, A, ws.stack[X][cur[X]], base, (uint32_t)c, X, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
         HIP_TRY(launch_shade(s->dev, A, ws.stack[X][cur[X]], base, (uint32_t)c, D, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
-        uint64_t n[2];
-        if (int rc = read_counts(n[0], n[1])) return rc;
+        uint64_t n[4];
+        if (int rc = read_counts(n)) return rc;
         if (s->profiling) {
             float a = 0, b = 0;
             HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
@@ -805,51 +836,55 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
             s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
         }
         s->prof[5] += 1;
-        s->flow[1] += (double)c; s->flow[2] += (double)n[0]; s->flow[3] += (double)n[1];
+        s->flow[1] += (double)c;
+        for (int k = 0; k < 4; k++) s->flow[2 + k] += (double)n[k];
         count[X][cur[X]] -= c;
         count[X][cur[X] ^ 1] += n[X];
         count[Y][cur[Y]] += n[Y];
         if (n[X]) cur[X] ^= 1;
+        for (int k = 0; k < 2; k++) {
+            scount[k] += n[2 + k];
+            if (scount[k] >= target) if (int rc = drain(k)) return rc;
+        }
     }
+    for (int k = 0; k < 2; k++) if (int rc = drain(k)) return rc;
     return 0;
 }
+
+// Default size of a round (rays traced per launch).  Larger rounds mean fewer launches and fuller
+// persistent grids but cost workspace: measured on the 1024 x 1024 benchmark frame, 16 Mi rays a
+// round are within a few per cent of 64 Mi at a quarter of the memory.
+#define RT_DEFAULT_ROUND_RAYS (16ull << 20)
 
 static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStream_t st)
 {
     if (A.max_jump < 0 || A.max_jump > 60) return fail("render: max_jump must be in [0,60]");
     if (total_items == 0) return 0;
-    const uint64_t max_push = (uint64_t)s->max_push;
-    // Rays per round.  Large rounds keep the persistent grid busy and mean fewer launches (fewer
-    // launch tails); they cost only stack memory, so by default the four stacks take a little over
-    // half of the device memory that is free, up to 64 Mi rays a round (37 GB a stack for two pushes
-    // per ray on a 288 GB part).  RT_WAVEFRONT_RAYS overrides.
-    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", 0);
-    if (target == 0) {
+    const uint64_t P = (uint64_t)s->max_push, L = (uint64_t)s->max_shadow;
+    // Rays per round: RT_WAVEFRONT_RAYS if set, else RT_DEFAULT_ROUND_RAYS; never more workspace
+    // than the scene's limit (rt_scene_set_workspace_limit) or, without one, a quarter of the
+    // device memory that is free.
+    uint64_t target = env_u64("RT_WAVEFRONT_RAYS", RT_DEFAULT_ROUND_RAYS);
+    if (target > total_items * (P ? P : 1)) target = total_items * (P ? P : 1);
+    if (target < RT_BLOCK) target = RT_BLOCK;
+    uint64_t limit = s->ws_limit;
+    if (limit == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        uint64_t held = 0;
-        for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) held += s->stack[c][k].cap * (RAY_FIELDS + 2) * sizeof(uint64_t);
-        const double budget = 0.55 * ((double)free_b + (double)held);
-        const double per_ray = 4.0 * (double)(max_push + 3) * (RAY_FIELDS + 2) * sizeof(uint64_t);
-        target = (uint64_t)(budget / per_ray) & ~((1ull << 20) - 1);
-        if (target > (64ull << 20)) target = 64ull << 20;
-        if (target < (1ull << 20)) target = 1ull << 20;
+        limit = (uint64_t)(0.25 * ((double)free_b + (double)s->ws_bytes));
     }
-    if (target > total_items * max_push) target = total_items * max_push;
-    if (target < RT_BLOCK) target = RT_BLOCK;
-    uint64_t cap = target * (max_push + 3);
-    while (cap >= 0xFFFFFFF0ull && target > (1u << 20)) { target >>= 1; cap = target * (max_push + 3); }
-    if (cap >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
-    // on a device with less free memory than that fall back to smaller rounds rather than fail
+    while (target > (1u << 16) && (workspace_bytes(target, P, L) > limit || target * (P + 3) >= 0xFFFFFFF0ull || target * (L + 1) >= 0xFFFFFFF0ull)) target >>= 1;
+    if (target * (P + 3) >= 0xFFFFFFF0ull || target * (L + 1) >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
+    // on a device with less memory than that fall back to smaller rounds rather than fail
     for (;;) {
-        const int rc = ensure_stacks(s, cap, st);
+        const int rc = ensure_workspace(s, workspace_bytes(target, P, L), st);
         if (rc == 0) break;
-        if (target <= (1u << 20)) return rc;
-        target >>= 1; cap = target * (max_push + 3);
+        if (target <= (1u << 16)) return rc;
+        target >>= 1;
     }
     WaveSpace ws;
-    for (int c = 0; c < 2; c++) for (int k = 0; k < 2; k++) ws.stack[c][k] = s->stack[c][k];
-    ws.d_ctrl = s->d_ctrl; ws.cap = cap; ws.target = target;
+    carve_workspace(s->ws_mem, target, P, L, ws);
+    ws.d_ctrl = s->d_ctrl;
     return wavefront_loop(s, ws, A, total_items, st);
 }
 
@@ -902,26 +937,18 @@ int rt_ray_color_noalloc(rt_scene *s, const rt_ray *rays, uint64_t n, double t0,
     HIP_TRY(hipSetDevice(s->device));
     void *base = nullptr;
     HIP_TRY(static_scratch(&base));
-    // 256 bytes of control words, then four stacks of `cap` slots of (RAY_FIELDS + 2) words
-    const uint64_t max_push = (uint64_t)s->max_push;
-    const uint64_t slot_bytes = (RAY_FIELDS + 2) * sizeof(uint64_t);
-    const uint64_t stack_bytes = (((uint64_t)RT_STATIC_SCRATCH_BYTES - 256u) / 4u) & ~(uint64_t)255u;
-    const uint64_t cap = (stack_bytes / slot_bytes) & ~(uint64_t)63u;
-    uint64_t target = cap / (max_push + 3);
+    // 256 bytes of control words, then the six stacks for the largest round that fits
+    const uint64_t P = (uint64_t)s->max_push, L = (uint64_t)s->max_shadow;
+    const uint64_t room = (uint64_t)RT_STATIC_SCRATCH_BYTES - 256u;
+    uint64_t target = room / (4 * (P + 3) * (RAY_FIELDS + 2) * sizeof(uint64_t) + 2 * (L + 1) * (SH_FIELDS * sizeof(uint64_t) + sizeof(uint32_t)));
+    target &= ~(uint64_t)63u;
+    while (target >= RT_BLOCK && workspace_bytes(target, P, L) > room) target -= 64;
     if (target < RT_BLOCK) return fail("rt_ray_color_noalloc: the scene's materials and lights append more rays per hit than the static workspace holds");
-    if (target > n * max_push) target = n * max_push;
+    if (target > n * (P ? P : 1)) target = n * (P ? P : 1);
     if (target < RT_BLOCK) target = RT_BLOCK;
     WaveSpace ws;
+    carve_workspace((unsigned char *)base + 256, target, P, L, ws);
     ws.d_ctrl = (uint32_t *)base;
-    for (int c = 0; c < 2; c++)
-        for (int k = 0; k < 2; k++) {
-            uint64_t *m = (uint64_t *)((unsigned char *)base + 256 + (uint64_t)(2 * c + k) * stack_bytes);
-            ws.stack[c][k].f = m;
-            ws.stack[c][k].hit_t = (double *)(m + cap * RAY_FIELDS);
-            ws.stack[c][k].hit_id = m + cap * (RAY_FIELDS + 1);
-            ws.stack[c][k].cap = cap;
-        }
-    ws.cap = cap; ws.target = target;
     A.batch = 1; A.rays = rays; A.t0 = t0; A.t1 = t1; A.jumptime = jumptime;
     A.out = out; A.counters = counters;
     HIP_TRY(hipMemsetAsync(out, 0, n * 3 * sizeof(double), (hipStream_t)stream));
@@ -957,7 +984,7 @@ int rt_scene_set_profiling(rt_scene *s, int enable)
 {
     if (!s) return fail("rt_scene_set_profiling: null scene");
     HIP_TRY(hipSetDevice(s->device));
-    if (enable) for (int k = 0; k < 3; k++) if (!s->ev[k]) HIP_TRY(hipEventCreate(&s->ev[k]));
+    if (enable) for (int k = 0; k < 5; k++) if (!s->ev[k]) HIP_TRY(hipEventCreate(&s->ev[k]));
     s->profiling = enable ? 1 : 0;
     return 0;
 }
@@ -970,12 +997,25 @@ int rt_scene_get_profile(rt_scene *s, double out[6], int reset)
     return 0;
 }
 
-int rt_scene_get_ray_flow(rt_scene *s, double out[4], int reset)
+int rt_scene_get_ray_flow(rt_scene *s, double out[6], int reset)
 {
     if (!s || !out) return fail("rt_scene_get_ray_flow: null argument");
-    for (int k = 0; k < 4; k++) out[k] = s->flow[k];
-    if (reset) for (int k = 0; k < 4; k++) s->flow[k] = 0;
+    for (int k = 0; k < 6; k++) out[k] = s->flow[k];
+    if (reset) for (int k = 0; k < 6; k++) s->flow[k] = 0;
     return 0;
+}
+
+int rt_scene_set_workspace_limit(rt_scene *s, uint64_t bytes)
+{
+    if (!s) return fail("rt_scene_set_workspace_limit: null scene");
+    s->ws_limit = bytes;
+    return 0;
+}
+
+int64_t rt_scene_workspace_bytes(const rt_scene *s)
+{
+    if (!s) { fail("rt_scene_workspace_bytes: null scene"); return -1; }
+    return (int64_t)s->ws_bytes;
 }
 
 int rt_resolve_bgr8(const double *radiance_sum, int w, int h, int spp, uint8_t *bgr, void *stream)

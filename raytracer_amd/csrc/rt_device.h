@@ -74,14 +74,16 @@ enum { RT_BLOCK = 256 };
 //   k_generate  appends camera rays for the next (pixel, sample) work items,
 //   k_trace     finds the closest hit of every ray of the chunk on top of the source stack,
 //   k_shade     consumes the hits: adds radiance to the pixel sums and appends the follow-up
-//               rays (bounce rays and shadow rays) to the destination stacks.
-// A ray record is 12 eight-byte words stored field-major (one array per field), so that the
-// lanes of a wave read and write consecutive addresses.
-enum { RAY_EX = 0, RAY_EY, RAY_EZ, RAY_DX, RAY_DY, RAY_DZ, RAY_T1, RAY_WX, RAY_WY, RAY_WZ, RAY_KEY, RAY_META, RAY_FIELDS };
-enum { RAY_RADIANCE = 0, RAY_SHADOW = 1 };
+//               rays (bounce rays and shadow rays) to the destination stacks,
+//   k_trace_shadow  finds out whether a shadow ray is blocked and, if not, delivers its radiance.
+// A pending radiance ray (camera ray or bounce ray) is 11 eight-byte words stored field-major (one
+// array per field), so that the lanes of a wave read and write consecutive addresses.  Its window
+// is not stored: a first ray uses the caller's [t0, t1], every other one [ZERO, INFINITE]
+// (scene.cpp:247,265,283,301).
+enum { RAY_EX = 0, RAY_EY, RAY_EZ, RAY_DX, RAY_DY, RAY_DZ, RAY_WX, RAY_WY, RAY_WZ, RAY_KEY, RAY_META, RAY_FIELDS };
 // RAY_META: bits 0-31 pixel (or ray index in batch mode), 32-55 sample index, 56-61 depth
-// (the jumpTime argument of rayColor), 62 E flag, 63 kind (RAY_SHADOW).  A ray whose depth is
-// the call's initial depth is a first ray and uses the caller's [t0,t1] window.
+// (the jumpTime argument of rayColor), 62 E flag.  A ray whose depth is the call's initial depth
+// and whose E flag is set is a first ray.
 
 struct RayStack {
     uint64_t *f;        // RAY_FIELDS arrays of `cap` words each: field k at f + k*cap
@@ -90,14 +92,27 @@ struct RayStack {
     uint64_t  cap;
 };
 
-// Follow-up rays are appended to one of two stacks by class: class 1 rays reach the root box of
-// an octree with inner nodes (they will run node and triangle steps), class 0 rays do not (they
-// finish within object phases).  Tracing the classes in separate launches keeps the lanes of a
-// wave in step; the class never changes what a ray returns.
+// A shadow ray (scene.cpp:235-238) is terminal: the closest-hit kernel itself adds the radiance it
+// carries to its pixel when nothing lies in its window, so it needs no key, no depth, no hit
+// record and never reaches the shading kernel.  10 eight-byte words (origin, direction, window
+// end, radiance) and the pixel index, field-major.
+enum { SH_EX = 0, SH_EY, SH_EZ, SH_DX, SH_DY, SH_DZ, SH_T1, SH_CX, SH_CY, SH_CZ, SH_FIELDS };
+struct ShadowStack {
+    uint64_t *f;        // SH_FIELDS arrays of `cap` words
+    uint32_t *pix;      // cap
+    uint64_t  cap;
+};
+
+// Follow-up rays are appended by class: class 1 rays reach the root box of an octree with inner
+// nodes (they will run node and triangle steps), class 0 rays do not (they finish within object
+// phases).  Tracing the classes in separate launches keeps the lanes of a wave in step; the class
+// never changes what a ray returns.
 struct RayDest {
-    RayStack  q[2];
-    uint64_t  base[2];      // first free slot of each stack
-    uint32_t *count;        // count[0], count[1]: rays appended by the running kernel (zeroed by the host)
+    RayStack    q[2];       // radiance rays by class
+    ShadowStack sq[2];      // shadow rays by class
+    uint64_t    base[2];    // first free slot of each radiance stack
+    uint64_t    sbase[2];   // first free slot of each shadow stack
+    uint32_t   *count;      // count[0..1] radiance, count[2..3] shadow rays appended by the running kernel (zeroed by the host)
 };
 
 // The workspace of the entry point that allocates nothing (rt_ray_color_noalloc): a file-scope

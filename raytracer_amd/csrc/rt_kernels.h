@@ -17,6 +17,9 @@ hipError_t launch_generate(const DevScene &S, const WaveArgs &A, const RayDest &
 // ray_class: the class of the chunk's rays (see RayDest)
 hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
                         int ray_class, hipStream_t st);
+// the shadow test of a chunk of a shadow stack; unblocked rays add their radiance to A.out
+hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const ShadowStack &q, uint64_t base,
+                               uint32_t count, int ray_class, hipStream_t st);
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
                         const RayDest &dst, hipStream_t st);
 // Address, on the CURRENT device, of the library's static workspace (RT_STATIC_SCRATCH_BYTES bytes,

@@ -256,7 +256,7 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 #define RT_PRE 16
 #endif
 #ifndef RT_WT
-#define RT_WT 8
+#define RT_WT 24
 #endif
 enum { TM_FETCH = 0, TM_OBJ = 1, TM_NODE = 2, TM_POP = 3, TM_TRI = 4, TM_EXIT = 5 };
 // flag in TravState::oi while the lane's ray is expressed in an implicit surface's own frame
@@ -1380,17 +1380,26 @@ __device__ inline bool refract_dir(V3 d, V3 normal, double n, V3 &t)
 // every contribution is added to its pixel's sum with a hardware fp64 atomic.  Random numbers
 // are keyed by a ray's position in the path tree, so the order in which rays are served does
 // not change any path; only the order of the fp64 additions into a pixel varies.
-__device__ __forceinline__ uint64_t pack_meta(uint32_t pix, uint32_t k, int32_t jump, int32_t E, int32_t kind)
+__device__ __forceinline__ uint64_t pack_meta(uint32_t pix, uint32_t k, int32_t jump, int32_t E)
 {
-    return (uint64_t)pix | ((uint64_t)(k & 0xFFFFFFu) << 32) | ((uint64_t)(jump & 63) << 56) | ((uint64_t)(E & 1) << 62) | ((uint64_t)(kind & 1) << 63);
+    return (uint64_t)pix | ((uint64_t)(k & 0xFFFFFFu) << 32) | ((uint64_t)(jump & 63) << 56) | ((uint64_t)(E & 1) << 62);
 }
-__device__ __forceinline__ void ray_store(const RayStack &q, uint64_t slot, V3 e, V3 d, double t1, V3 w, uint64_t key, uint64_t meta)
+__device__ __forceinline__ void shadow_store(const ShadowStack &q, uint64_t slot, V3 e, V3 d, double t1, V3 contrib, uint32_t pix)
+{
+    uint64_t *b = q.f + slot;
+    const uint64_t c = q.cap;
+    b[SH_EX * c] = __double_as_longlong(e.x); b[SH_EY * c] = __double_as_longlong(e.y); b[SH_EZ * c] = __double_as_longlong(e.z);
+    b[SH_DX * c] = __double_as_longlong(d.x); b[SH_DY * c] = __double_as_longlong(d.y); b[SH_DZ * c] = __double_as_longlong(d.z);
+    b[SH_T1 * c] = __double_as_longlong(t1);
+    b[SH_CX * c] = __double_as_longlong(contrib.x); b[SH_CY * c] = __double_as_longlong(contrib.y); b[SH_CZ * c] = __double_as_longlong(contrib.z);
+    q.pix[slot] = pix;
+}
+__device__ __forceinline__ void ray_store(const RayStack &q, uint64_t slot, V3 e, V3 d, V3 w, uint64_t key, uint64_t meta)
 {
     uint64_t *b = q.f + slot;
     const uint64_t c = q.cap;
     b[RAY_EX * c] = __double_as_longlong(e.x); b[RAY_EY * c] = __double_as_longlong(e.y); b[RAY_EZ * c] = __double_as_longlong(e.z);
     b[RAY_DX * c] = __double_as_longlong(d.x); b[RAY_DY * c] = __double_as_longlong(d.y); b[RAY_DZ * c] = __double_as_longlong(d.z);
-    b[RAY_T1 * c] = __double_as_longlong(t1);
     b[RAY_WX * c] = __double_as_longlong(w.x); b[RAY_WY * c] = __double_as_longlong(w.y); b[RAY_WZ * c] = __double_as_longlong(w.z);
     b[RAY_KEY * c] = key;
     b[RAY_META * c] = meta;
@@ -1417,18 +1426,18 @@ __device__ __forceinline__ int ray_class(const DevScene &S, V3 e, V3 d, double t
     return cls;
 }
 
-// Slot reservation for a block that appends rays: every wave passes its per-class totals, one
-// atomic per class and block reserves the slots, and each wave gets the first slot of its share
-// per class.  All threads of the block must call this.
-struct SlotCursor { uint64_t s[2]; };
-__device__ __forceinline__ SlotCursor block_reserve(const RayDest &D, uint32_t wave_n0, uint32_t wave_n1)
+// Slot reservation for a block that appends rays: every wave passes its totals per destination
+// (radiance class 0 / 1, shadow class 0 / 1), one atomic per destination and block reserves the
+// slots, and each wave gets the first slot of its share.  All threads of the block must call this.
+struct SlotCursor { uint64_t s[4]; };
+__device__ __forceinline__ SlotCursor block_reserve(const RayDest &D, uint32_t wave_r0, uint32_t wave_r1, uint32_t wave_s0, uint32_t wave_s1)
 {
-    __shared__ uint32_t wave_tot[2][RT_BLOCK / 64], block_base[2];
+    __shared__ uint32_t wave_tot[4][RT_BLOCK / 64], block_base[4];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __syncthreads();                     // an earlier reservation of this block has been read by every wave
-    if (lane == 0) { wave_tot[0][wv] = wave_n0; wave_tot[1][wv] = wave_n1; }
+    if (lane == 0) { wave_tot[0][wv] = wave_r0; wave_tot[1][wv] = wave_r1; wave_tot[2][wv] = wave_s0; wave_tot[3][wv] = wave_s1; }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 4) {
         uint32_t tot = 0;
         for (int i = 0; i < RT_BLOCK / 64; i++) tot += wave_tot[threadIdx.x][i];
         block_base[threadIdx.x] = tot ? atomicAdd(D.count + threadIdx.x, tot) : 0u;
@@ -1437,17 +1446,21 @@ __device__ __forceinline__ SlotCursor block_reserve(const RayDest &D, uint32_t w
     SlotCursor c;
     c.s[0] = D.base[0] + block_base[0];
     c.s[1] = D.base[1] + block_base[1];
-    for (uint32_t i = 0; i < wv; i++) { c.s[0] += wave_tot[0][i]; c.s[1] += wave_tot[1][i]; }
+    c.s[2] = D.sbase[0] + block_base[2];
+    c.s[3] = D.sbase[1] + block_base[3];
+    for (uint32_t i = 0; i < wv; i++) { c.s[0] += wave_tot[0][i]; c.s[1] += wave_tot[1][i]; c.s[2] += wave_tot[2][i]; c.s[3] += wave_tot[3][i]; }
     return c;
 }
-// The lanes with `want` append one ray each (class `cls`) at the cursor and move it on.
-// m1 = ballot(want && cls), m0 = ballot(want && !cls), computed by the caller before reserving.
-__device__ __forceinline__ uint64_t take_slot(SlotCursor &c, unsigned long long m0, unsigned long long m1, int cls)
+// The lanes with `want` append one ray each (class `cls`) at the cursor pair `pair` (0 = radiance
+// stacks, 1 = shadow stacks) and move it on.  m1 = ballot(want && cls), m0 = ballot(want && !cls),
+// computed by the caller before reserving.
+__device__ __forceinline__ uint64_t take_slot(SlotCursor &c, int pair, unsigned long long m0, unsigned long long m1, int cls)
 {
     const unsigned long long lt = (1ull << (threadIdx.x & 63u)) - 1ull;
-    const uint64_t slot = cls ? c.s[1] + (uint32_t)__popcll(m1 & lt) : c.s[0] + (uint32_t)__popcll(m0 & lt);
-    c.s[0] += (uint32_t)__popcll(m0);
-    c.s[1] += (uint32_t)__popcll(m1);
+    uint64_t *s = c.s + 2 * pair;
+    const uint64_t slot = cls ? s[1] + (uint32_t)__popcll(m1 & lt) : s[0] + (uint32_t)__popcll(m0 & lt);
+    s[0] += (uint32_t)__popcll(m0);
+    s[1] += (uint32_t)__popcll(m1);
     return slot;
 }
 
@@ -1480,9 +1493,55 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(DevScene S, WaveArgs A, R
     }
     const int cls = live ? ray_class(S, e, d, t1) : 0;
     const unsigned long long m0 = __ballot(live && !cls), m1 = __ballot(live && cls);
-    SlotCursor cur = block_reserve(D, (uint32_t)__popcll(m0), (uint32_t)__popcll(m1));
-    const uint64_t slot = take_slot(cur, m0, m1, cls);
-    if (live) ray_store(D.q[cls], slot, e, d, t1, mk(1, 1, 1), path_root_key(A.seed, pix, k), pack_meta(pix, k, A.jumptime, 1, RAY_RADIANCE));
+    SlotCursor cur = block_reserve(D, (uint32_t)__popcll(m0), (uint32_t)__popcll(m1), 0u, 0u);
+    const uint64_t slot = take_slot(cur, 0, m0, m1, cls);
+    if (live) ray_store(D.q[cls], slot, e, d, mk(1, 1, 1), path_root_key(A.seed, pix, k), pack_meta(pix, k, A.jumptime, 1));
+}
+
+__device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
+{
+    if (v.x != 0.0) unsafeAtomicAdd(out + 3ull * pix, v.x);
+    if (v.y != 0.0) unsafeAtomicAdd(out + 3ull * pix + 1, v.y);
+    if (v.z != 0.0) unsafeAtomicAdd(out + 3ull * pix + 2, v.z);
+}
+
+// The shadow test for the chunk [base, base+count) of a shadow stack: group_->calHit(newray, ZERO,
+// dist - ZERO, nullptr) (scene.cpp:236), the same closest-hit search as for any ray (the reference
+// does not stop at the first blocker, and the work counters count that search); a ray that finds
+// nothing adds its radiance to its pixel (scene.cpp:238) right here.
+struct ShadowSrc {
+    ShadowStack q; uint64_t base; uint32_t n; double *out;
+    __device__ double f(uint64_t slot, int field) const { return __longlong_as_double(q.f[(uint64_t)field * q.cap + slot]); }
+    __device__ uint32_t count() const { return n; }
+    __device__ bool load(uint32_t i, V3 &e, V3 &d, double &t0, double &t1) const
+    {
+        const uint64_t slot = base + i;
+        e = mk(f(slot, SH_EX), f(slot, SH_EY), f(slot, SH_EZ));
+        d = mk(f(slot, SH_DX), f(slot, SH_DY), f(slot, SH_DZ));
+        t0 = RT_ZERO;
+        t1 = f(slot, SH_T1);
+        return true;
+    }
+    __device__ void reload(uint32_t i, V3 &e, V3 &d) const
+    {
+        const uint64_t slot = base + i;
+        e = mk(f(slot, SH_EX), f(slot, SH_EY), f(slot, SH_EZ));
+        d = mk(f(slot, SH_DX), f(slot, SH_DY), f(slot, SH_DZ));
+    }
+    __device__ void store(uint32_t i, bool hit, const Hit &) const
+    {
+        if (hit) return;
+        const uint64_t slot = base + i;
+        add_radiance(out, q.pix[slot], mk(f(slot, SH_CX), f(slot, SH_CY), f(slot, SH_CZ)));
+    }
+};
+RT_TRACE_ATTR
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow(DevScene S, ShadowSrc src, uint32_t *next, uint32_t batch_max, uint64_t *counters)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    Counters c = { 0, 0, 0, 0 };
+    trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
+    flush_counters(counters, c);
 }
 
 // Closest hit for the chunk [base, base+count) of a ray stack.
@@ -1494,14 +1553,13 @@ struct StackSrc {
         const uint64_t slot = base + i;
         const uint64_t meta = q.f[(uint64_t)RAY_META * q.cap + slot];
         const int jump = (int)((meta >> 56) & 63);
-        const bool shadow = (meta >> 63) != 0;
         // depth cut-off (scene.cpp:196-198) happens before any intersection work
-        if (!shadow && jump + 1 > A.max_jump) return false;
+        if (jump + 1 > A.max_jump) return false;
         e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
         d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
-        const bool first = !shadow && jump == A.jumptime && ((meta >> 62) & 1);
+        const bool first = jump == A.jumptime && ((meta >> 62) & 1);
         t0 = first ? A.t0 : RT_ZERO;
-        t1 = ray_f(q, slot, RAY_T1);
+        t1 = first ? A.t1 : RT_INFINITE;
         return true;
     }
     __device__ void reload(uint32_t i, V3 &e, V3 &d) const
@@ -1526,13 +1584,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, ui
     flush_counters(src.A.counters, c);
 }
 
-__device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
-{
-    if (v.x != 0.0) unsafeAtomicAdd(out + 3ull * pix, v.x);
-    if (v.y != 0.0) unsafeAtomicAdd(out + 3ull * pix + 1, v.y);
-    if (v.z != 0.0) unsafeAtomicAdd(out + 3ull * pix + 2, v.z);
-}
-
 // Consume the hits of chunk [base, base+count) of `src`; follow-up rays are appended to D.
 // KINDS says which material features the scene's objects use (DevScene::shade_kinds): 1 = a mirror
 // lobe, 2 = a dielectric lobe, 4 = the Phong / Whitted branch (materials without MONTECARLO, Perlin
@@ -1551,7 +1602,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     const uint64_t meta = src.f[(uint64_t)RAY_META * src.cap + slot];
     const uint32_t pix = (uint32_t)meta, k = (uint32_t)(meta >> 32) & 0xFFFFFFu;
     const int jump = (int)((meta >> 56) & 63), E = (int)((meta >> 62) & 1);
-    const bool shadow = (meta >> 63) != 0;
     const uint64_t id = src.hit_id[slot];
     const bool hit = id != ~0ull;
     const V3 W = mk(ray_f(src, slot, RAY_WX), ray_f(src, slot, RAY_WY), ray_f(src, slot, RAY_WZ));
@@ -1560,12 +1610,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
     V3 sum = mk(0, 0, 0);                 // everything this ray adds to its pixel
     bool shade = false;
     if (live) {
-        if (shadow) { if (!hit) sum = W; }                                   // scene.cpp:236-238
-        else if (!hit) sum = had(W, ld3(S.background));                      // scene.cpp:196-198, 378-380
+        if (!hit) sum = had(W, ld3(S.background));                           // scene.cpp:196-198, 378-380
         else shade = true;
     }
-    // values every push site needs; shadow rays and misses (about half of all rays, and whole
-    // waves of them, since rays of one kind are appended next to each other) skip these loads
+    // values every push site needs; misses skip these loads
     V3 re = mk(0, 0, 0), rd = mk(0, 0, 1);
     uint64_t key = 0;
     double ht = 0;
@@ -1680,9 +1728,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         if (li == 0) { want0 = want; ldir0 = ldir; contrib0 = contrib; dist0 = dist; continue; }
         const int cls = want ? ray_class(S, p, ldir, dist - RT_ZERO) : 0;
         const unsigned long long m0 = __ballot(want && !cls), m1 = __ballot(want && cls);
-        SlotCursor cur = block_reserve(D, (uint32_t)__popcll(m0), (uint32_t)__popcll(m1));
-        const uint64_t slot = take_slot(cur, m0, m1, cls);
-        if (want) ray_store(D.q[cls], slot, p, ldir, dist - RT_ZERO, contrib, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
+        SlotCursor cur = block_reserve(D, 0u, 0u, (uint32_t)__popcll(m0), (uint32_t)__popcll(m1));
+        const uint64_t slot = take_slot(cur, 1, m0, m1, cls);
+        if (want) shadow_store(D.sq[cls], slot, p, ldir, dist - RT_ZERO, contrib, pix);
     }
 
     // ---- mirror lobe, scene.cpp:249-266
@@ -1749,20 +1797,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         const unsigned long long a2 = __ballot(lobeS && !k2), b2 = __ballot(lobeS && k2);
         const unsigned long long a3 = __ballot(lobeT && !k3), b3 = __ballot(lobeT && k3);
         const unsigned long long a4 = __ballot(wantT && !k4), b4 = __ballot(wantT && k4);
-        SlotCursor cur = block_reserve(D, (uint32_t)(__popcll(a0) + __popcll(a1) + __popcll(a2) + __popcll(a3) + __popcll(a4)),
-                                       (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4)));
+        SlotCursor cur = block_reserve(D, (uint32_t)(__popcll(a0) + __popcll(a2) + __popcll(a3) + __popcll(a4)),
+                                       (uint32_t)(__popcll(b0) + __popcll(b2) + __popcll(b3) + __popcll(b4)),
+                                       (uint32_t)__popcll(a1), (uint32_t)__popcll(b1));
         uint64_t slot;
-        slot = take_slot(cur, a0, b0, k0);
-        if (lobeN) ray_store(D.q[k0], slot, p, dn, RT_INFINITE, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0, RAY_RADIANCE));
-        slot = take_slot(cur, a1, b1, k1);
-        if (want0) ray_store(D.q[k1], slot, p, ldir0, dist0 - RT_ZERO, contrib0, 0, pack_meta(pix, k, 0, 0, RAY_SHADOW));
-        slot = take_slot(cur, a2, b2, k2);
-        if (lobeS) ray_store(D.q[k2], slot, p, md, RT_INFINITE, had(W, mweight), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        slot = take_slot(cur, 0, a0, b0, k0);
+        if (lobeN) ray_store(D.q[k0], slot, p, dn, had(W, mcolor), hash2(key, BR_DIFFUSE), pack_meta(pix, k, jt + 1, 0));
+        slot = take_slot(cur, 1, a1, b1, k1);
+        if (want0) shadow_store(D.sq[k1], slot, p, ldir0, dist0 - RT_ZERO, contrib0, pix);
+        slot = take_slot(cur, 0, a2, b2, k2);
+        if (lobeS) ray_store(D.q[k2], slot, p, md, had(W, mweight), hash2(key, BR_SPECULAR), pack_meta(pix, k, jt, 1));
         // reflected ray: weight k (total internal reflection) or k*R
-        slot = take_slot(cur, a3, b3, k3);
-        if (lobeT) ray_store(D.q[k3], slot, p, r, RT_INFINITE, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
-        slot = take_slot(cur, a4, b4, k4);
-        if (wantT) ray_store(D.q[k4], slot, p, rfr, RT_INFINITE, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1, RAY_RADIANCE));
+        slot = take_slot(cur, 0, a3, b3, k3);
+        if (lobeT) ray_store(D.q[k3], slot, p, r, had(W, tir ? kk : kk * R), hash2(key, BR_REFLECT), pack_meta(pix, k, jt, 1));
+        slot = take_slot(cur, 0, a4, b4, k4);
+        if (wantT) ray_store(D.q[k4], slot, p, rfr, had(W, kk * (1 - R)), hash2(key, BR_REFRACT), pack_meta(pix, k, jt, 1));
     }
 
     if (live) add_radiance(A.out, pix, sum);
@@ -1793,14 +1842,14 @@ __global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, int
 // Persistent grids: no more blocks than stay resident, no more than the rays need.
 static unsigned engine_blocks(uint64_t items, int num_cu, const void *kernel)
 {
-    static thread_local const void *cached_k[3] = { nullptr, nullptr, nullptr };
-    static thread_local int cached_v[3] = { 0, 0, 0 };
+    static thread_local const void *cached_k[4] = { nullptr, nullptr, nullptr, nullptr };
+    static thread_local int cached_v[4] = { 0, 0, 0, 0 };
     int per_cu = 0;
-    for (int i = 0; i < 3; i++) if (cached_k[i] == kernel) per_cu = cached_v[i];
+    for (int i = 0; i < 4; i++) if (cached_k[i] == kernel) per_cu = cached_v[i];
     if (!per_cu) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        for (int i = 0; i < 3; i++) if (!cached_k[i]) { cached_k[i] = kernel; cached_v[i] = per_cu; break; }
+        for (int i = 0; i < 4; i++) if (!cached_k[i]) { cached_k[i] = kernel; cached_v[i] = per_cu; break; }
     }
     uint64_t resident = (uint64_t)(num_cu > 0 ? num_cu : 256) * (uint64_t)per_cu;
     uint64_t need = (items + RT_BLOCK - 1) / RT_BLOCK;
@@ -1840,6 +1889,17 @@ hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const Wav
     hipError_t e = hipMemsetAsync(next, 0, 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next, ray_class ? (uint32_t)RT_BATCH1 : (uint32_t)RT_BATCH0);
+    return hipGetLastError();
+}
+hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const ShadowStack &q, uint64_t base,
+                               uint32_t count, int ray_class, hipStream_t st)
+{
+    if (!count) return hipSuccess;
+    ShadowSrc src = { q, base, count, A.out };
+    hipError_t e = hipMemsetAsync(next, 0, 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_shadow, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow)), dim3(RT_BLOCK), 0, st, S, src, next,
+                       ray_class ? (uint32_t)RT_BATCH1 : (uint32_t)RT_BATCH0, A.counters);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,

@@ -20,11 +20,13 @@ EXPORTS = (
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_ray_color_noalloc", "rt_render",
-    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_scene_get_ray_flow", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
+    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_scene_get_ray_flow", "rt_scene_set_workspace_limit", "rt_scene_workspace_bytes", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
     "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_open_mjpg", "rt_avi_add_frame", "rt_avi_close",
     "rt_perlin_time_changed", "rt_scene_set_perlin",
+    "rt_comm_create", "rt_comm_unique_id", "rt_comm_init_rank", "rt_comm_size", "rt_comm_destroy", "rt_reduce_and_resolve",
+    "rt_multi_create", "rt_multi_size", "rt_multi_scene", "rt_multi_render", "rt_multi_destroy",
 )
 
 _lib = None
@@ -64,6 +66,9 @@ def lib():
     L.rt_scene_set_profiling.argtypes = [_vp, _int]
     L.rt_scene_get_profile.argtypes = [_vp, _dp, _int]
     L.rt_scene_get_ray_flow.argtypes = [_vp, _dp, _int]
+    L.rt_scene_set_workspace_limit.argtypes = [_vp, _u64]
+    L.rt_scene_workspace_bytes.restype = C.c_int64
+    L.rt_scene_workspace_bytes.argtypes = [_vp]
     L.rt_resolve_bgr8.argtypes = [_vp, _int, _int, _int, _vp, _vp]
     L.rt_resolve_bgr8_host.argtypes = [_vp, _int, _int, _int, _vp]
     L.rt_save_bmp.argtypes = [_vp, _int, _int, C.c_char_p]
@@ -84,6 +89,18 @@ def lib():
     L.rt_scene_implicit_stats.argtypes = [_vp, _int, C.POINTER(C.c_uint64)]
     L.rt_scene_implicit_boxes.restype = C.c_int64
     L.rt_scene_implicit_boxes.argtypes = [_vp, _int, _vp, _u64]
+    L.rt_comm_create.argtypes = [_int, C.POINTER(_int), C.POINTER(_vp)]
+    L.rt_comm_unique_id.argtypes = [_vp]
+    L.rt_comm_init_rank.argtypes = [_vp, _int, _int, _int, C.POINTER(_vp)]
+    L.rt_comm_size.argtypes = [_vp]
+    L.rt_comm_destroy.argtypes = [_vp]
+    L.rt_reduce_and_resolve.argtypes = [_vp, _int, _vp, _int, _int, _int, _int, _vp, _vp]
+    L.rt_multi_create.argtypes = [C.POINTER(SceneDescC), C.POINTER(_int), _int, _int, C.POINTER(_vp)]
+    L.rt_multi_size.argtypes = [_vp]
+    L.rt_multi_scene.restype = _vp
+    L.rt_multi_scene.argtypes = [_vp, _int]
+    L.rt_multi_render.argtypes = [_vp, C.POINTER(CameraC), C.POINTER(RenderParamsC), _int, _vp, _vp, _vp]
+    L.rt_multi_destroy.argtypes = [_vp]
     _lib = L
     return L
 
@@ -286,9 +303,16 @@ class HipScene:
         return dict(zip(("trace_launches", "trace_ms", "shade_launches", "shade_ms", "generate_launches", "rounds"), out[:]))
 
     def get_ray_flow(self, reset=True):
-        out = (C.c_double * 4)()
+        out = (C.c_double * 6)()
         _chk(lib().rt_scene_get_ray_flow(self._h, out, 1 if reset else 0), "rt_scene_get_ray_flow")
-        return dict(zip(("first_rays", "shaded_in", "appended_class0", "appended_class1"), out[:]))
+        return dict(zip(("first_rays", "shaded_in", "bounce_class0", "bounce_class1", "shadow_class0", "shadow_class1"), out[:]))
+
+    def set_workspace_limit(self, nbytes):
+        """Upper bound on the device memory of the pending-ray stacks (0 = default policy)."""
+        _chk(lib().rt_scene_set_workspace_limit(self._h, int(nbytes)), "rt_scene_set_workspace_limit")
+
+    def workspace_bytes(self):
+        return int(lib().rt_scene_workspace_bytes(self._h))
 
     def implicit_stats(self, kind):
         out = (C.c_uint64 * 6)()
@@ -321,3 +345,74 @@ class HipScene:
 
 def resolve_bgr8_dev(radiance_sum_ptr, w, h, spp, bgr_ptr, stream=0):
     _chk(lib().rt_resolve_bgr8(radiance_sum_ptr, w, h, int(spp), bgr_ptr, stream or None), "rt_resolve_bgr8")
+
+
+REDUCE_RCCL, REDUCE_HOST = 0, 1
+
+
+class Comm:
+    """rt_comm: the RCCL communicator of the frame's one reduce.  Comm(devices=[...]) for members in
+    this process; Comm(unique_id=..., nranks=, rank=, device=) for one process per GPU."""
+
+    def __init__(self, devices=None, unique_id=None, nranks=0, rank=0, device=0):
+        self._h = _vp()
+        if devices is not None:
+            arr = (_int * len(devices))(*devices)
+            _chk(lib().rt_comm_create(len(devices), arr, C.byref(self._h)), "rt_comm_create")
+        else:
+            buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+            _chk(lib().rt_comm_init_rank(buf, int(nranks), int(rank), int(device), C.byref(self._h)), "rt_comm_init_rank")
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _chk(lib().rt_comm_unique_id(buf), "rt_comm_unique_id")
+        return bytes(buf)
+
+    def size(self):
+        return lib().rt_comm_size(self._h)
+
+    def reduce_and_resolve(self, member, radiance_sum_ptr, w, h, spp, bgr_ptr=0, tone=TONE_NONE, stream=0):
+        _chk(lib().rt_reduce_and_resolve(self._h, int(member), radiance_sum_ptr, w, h, int(spp), int(tone), bgr_ptr or None, stream or None),
+             "rt_reduce_and_resolve")
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            lib().rt_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiScene:
+    """rt_multi: one scene handle and one host thread per listed device, samples dealt to them."""
+
+    def __init__(self, desc, devices, reduce_mode=REDUCE_RCCL):
+        d, keep = desc.to_c()
+        arr = (_int * len(devices))(*devices)
+        self._h = _vp()
+        _chk(lib().rt_multi_create(C.byref(d), arr, len(devices), int(reduce_mode), C.byref(self._h)), "rt_multi_create")
+        del keep
+
+    def render(self, cam, params, tone=TONE_NONE):
+        """-> (radiance sums (h, w, 3), bytes (h, w, 3), counters)"""
+        img = np.zeros((params.height, params.width, 3), np.float64)
+        bgr = np.zeros((params.height, params.width, 3), np.uint8)
+        cnt = np.zeros(4, np.uint64)
+        _chk(lib().rt_multi_render(self._h, C.byref(cam), C.byref(params), int(tone), _p(img), _p(bgr), _p(cnt)), "rt_multi_render")
+        return img, bgr, cnt
+
+    def close(self):
+        if getattr(self, "_h", None):
+            h, self._h = self._h, None
+            lib().rt_multi_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

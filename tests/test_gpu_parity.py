@@ -437,7 +437,8 @@ def test_profile_counters_are_consistent():
     c = hip.camera_init(**cam)
     _, cnt = sg.render(c, render_params(64, 64, 2, seed=1))
     p = sg.get_profile()
-    assert p["trace_launches"] >= 1 and p["trace_ms"] > 0 and p["shade_launches"] == p["trace_launches"]
+    # every round traces and shades one chunk of bounce rays; shadow-ray launches come on top
+    assert p["shade_launches"] >= 1 and p["trace_ms"] > 0 and p["trace_launches"] >= p["shade_launches"]
     assert int(cnt[0]) > 64 * 64 * 4
 
 
