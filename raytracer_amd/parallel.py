@@ -95,3 +95,65 @@ def render_frames(render_frame, nframes, rank=None, world=None, dst=0, dt=0.015)
         for f, img in part:
             frames[f] = img
     return frames
+
+
+class FrameSink:
+    """Takes finished 8-bit frames off the rendering stream so that frame f's trip to the host and
+    whatever is done with it there (`consume(f, array)`, e.g. the AVI writer: main.cpp:87-98 does
+    this inline, frame after frame) overlap the rendering of frame f + 1.
+
+    The renderer resolves into `device_buffer(f)` (two device buffers alternate) and calls
+    `submit(f)`; a side stream copies the buffer to pinned host memory once the rendering stream
+    has reached that point, and a worker thread waits for the copy and calls `consume`.  `close()`
+    drains.  torch is used for the buffers, the streams and the events only."""
+
+    def __init__(self, height, width, consume, device):
+        import queue
+        import threading
+        import torch
+        self._torch = torch
+        self._dev = [torch.empty(height, width, 3, dtype=torch.uint8, device=device) for _ in range(2)]
+        self._host = [torch.empty(height, width, 3, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._free = [threading.Semaphore(1), threading.Semaphore(1)]        # a buffer pair is reused only after its frame was consumed
+        self._copy = torch.cuda.Stream(device=device)
+        self._q = queue.Queue()
+        self._consume = consume
+        self._err = None
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def device_buffer(self, f):
+        """The device buffer frame f is to be resolved into (blocks while its previous frame is still on its way)."""
+        self._free[f & 1].acquire()
+        return self._dev[f & 1]
+
+    def submit(self, f):
+        torch = self._torch
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._copy):
+            self._copy.wait_event(done)
+            self._host[f & 1].copy_(self._dev[f & 1], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self._copy)
+        self._q.put((f, copied))
+
+    def _run(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            f, copied = item
+            try:
+                copied.synchronize()
+                self._consume(f, self._host[f & 1].numpy())
+            except Exception as e:           # reported by close()
+                self._err = e
+            finally:
+                self._free[f & 1].release()
+
+    def close(self):
+        self._q.put(None)
+        self._t.join()
+        if self._err is not None:
+            raise self._err

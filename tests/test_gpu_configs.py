@@ -118,6 +118,36 @@ def test_flythrough_frames_round_robin_through_avi(tmp_path):
         assert 10 * np.log10(255.0 ** 2 / max(((dec - src) ** 2).mean(), 1e-12)) > 35
 
 
+def test_frame_sink_delivers_every_frame_in_order_while_rendering_continues():
+    """parallel.FrameSink: frames resolved on the rendering stream reach the consumer (here the
+    AVI writer's input) complete and in order although their buffers are reused two frames later."""
+    import torch
+    from raytracer_amd.parallel import FrameSink
+    desc, cam = scenes.three_sphere_scene("face")
+    sg = hip.HipScene(desc)
+    W, H, n = 96, 64, 2
+    dev = torch.device("cuda:0")
+    img = torch.zeros(H, W, 3, dtype=torch.float64, device=dev)
+    got = []
+    sink = FrameSink(H, W, lambda f, arr: got.append((f, arr.copy())), dev)
+    want = []
+    stream = torch.cuda.current_stream().cuda_stream
+    for f in range(7):
+        c = hip.camera_init((0.3 * f, 2.0, 9.0), (0, 1, 0), (0, 1, 0), 40.0, W / H)
+        prm = render_params(W, H, n, seed=3)
+        img.zero_()
+        sg.render_dev(c, prm, img.data_ptr(), 0, stream)
+        hip.resolve_bgr8_dev(img.data_ptr(), W, H, n * n, sink.device_buffer(f).data_ptr(), stream)
+        sink.submit(f)
+        ref, _ = sg.render(c, prm)
+        want.append(hip.resolve_bgr8_host(ref, n * n))
+    sink.close()
+    assert [f for f, _ in got] == list(range(7))
+    for (f, a), b in zip(got, want):
+        assert (a != b).mean() < 1e-3, f                  # the two renders differ by the order of atomic additions only
+    assert np.abs(got[0][1].astype(int) - got[6][1].astype(int)).mean() > 0.5
+
+
 @pytest.mark.parametrize("n,m", [(5, 3), (2, 7), (1, 6)])
 def test_render_with_rectangular_jitter_table(n, m):
     """RTObject::setRandomSize(n, m) with n != m (RTObject.cpp:23-39,53-58): pixel jitter and the

@@ -43,12 +43,16 @@ for name in ("fetch", "write", "sq"):
                 summary.setdefault(k, {})[c] = {"sum": val, "dispatches": n[(k, c)]}
 
 
-def figures(k):
-    """Per-launch HBM bytes and VALU figures of one kernel.  FETCH_SIZE / WRITE_SIZE are reported in
+def figures(*kernels):
+    """Per-launch HBM bytes and VALU figures of one kernel, or of several taken together.  FETCH_SIZE / WRITE_SIZE are reported in
     KiB per dispatch; on gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes for wide loads,
     hence the factor 2 on the read side.  SQ_BUSY_CYCLES is summed over the 32 shader engines, each
     with 32 SIMDs (256 CUs x 4 / 32), and SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD."""
-    d = summary.get(k, {})
+    d = {}
+    for k in kernels:
+        for c, v in summary.get(k, {}).items():
+            e = d.setdefault(c, {"sum": 0.0, "dispatches": 0})
+            e["sum"] += v["sum"]; e["dispatches"] += v["dispatches"]
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
         return {}
     launches = d["FETCH_SIZE"]["dispatches"]
@@ -64,10 +68,8 @@ def figures(k):
 
 
 pmc = {"collected": f"{tag}, `bench.py --workload {workload} --steps 1 --warmup 0 --no-cpu-baseline`, FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes",
-       "trace": figures("rt::k_trace"), "shade": figures("rt::k_shade")}
-for extra in ("rt::k_trace_shadow",):
-    if extra in summary:
-        pmc[extra.split("::")[1]] = figures(extra)
+       "trace": figures("rt::k_trace", "rt::k_trace_shadow"), "shade": figures("rt::k_shade"),
+       "k_trace": figures("rt::k_trace"), "k_trace_shadow": figures("rt::k_trace_shadow")}
 json.dump(pmc, open(os.path.join(OUT, f"pmc_{workload}.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(OUT, f"{tag}_{workload}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(pmc, indent=1))
