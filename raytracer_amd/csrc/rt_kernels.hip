@@ -533,11 +533,11 @@ __device__ __forceinline__ bool sph_pass(const SphQ &q, const RayF &r)
 #endif
 #define RT_LANE_RECS 4           // records a lane pre-tests per chunk (their spheres are one 16-byte load)
 #ifndef RT_SEG_CAP
-#define RT_SEG_CAP 128           // segment table entries per wave: RT_SEG_CAP * RT_SEG records are scheduled per round
+#define RT_SEG_CAP 128           // segment table entries per wave, one of them the empty entry: (RT_SEG_CAP - 1) * RT_SEG records are scheduled per round
 #endif
 #define RT_SEG_ROUND_MAX 15      // most segments one owner lists per round (4 bits in the prefix sum)
 struct CoopLds {                 // per wave
-    uint64_t seg[RT_SEG_CAP];    // first record | owner lane << 32 | records in the segment << 40
+    uint64_t seg[RT_SEG_CAP];    // first record | owner lane << 32 | records in the segment << 40; behind the last one an empty entry
     uint32_t crec[RT_CAND_CAP];  // candidate's record index
     uint8_t  cown[RT_CAND_CAP];  // candidate's owner lane
     unsigned long long okey[64]; // per owner lane, per pass: smallest hit distance as an ordered integer
@@ -545,6 +545,13 @@ struct CoopLds {                 // per wave
     uint32_t oid[64];            //   that candidate's primitive id
 };
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+// the lanes for which p holds, as a mask (the predicate's own lane mask: no 0/1 value is formed)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// acc + the number of set bits of m below this lane
+__device__ __forceinline__ uint32_t count_below(unsigned long long m, uint32_t acc)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc));
+}
 // doubles (no NaN) <-> unsigned integers in the same order
 __device__ __forceinline__ unsigned long long ordered_key(double t)
 {
@@ -682,7 +689,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
             if (total == 0u) break;
             RT_TICK9(rays)
-            if (total > (uint32_t)RT_SEG_CAP) total = RT_SEG_CAP;                  // the rest waits for the next round
+            if (total > (uint32_t)RT_SEG_CAP - 1u) total = RT_SEG_CAP - 1u;        // the rest waits for the next round
             if (first > total) first = total;
             if (nseg > total - first) nseg = total - first;
 #pragma unroll 1
@@ -693,6 +700,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                     L.seg[first + j] = (unsigned long long)r0 | ((unsigned long long)lane << 32) | ((unsigned long long)cnt << 40);
                 }
             }
+            if (lane == 0) L.seg[total] = 0ull;                                     // what a chunk reads past the last segment
             if (nseg) { const uint32_t adv = nseg * RT_SEG; kcur = T.kend - kcur < adv ? T.kend : kcur + adv; }
             nchunk = (total + SEGS_PER_CHUNK - 1u) / SEGS_PER_CHUNK;
             RT_TICK9(inner)
@@ -711,8 +719,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                 const uint32_t r0 = sidx < total ? solo_base + sidx * RT_SEG : 0u;
                 return (unsigned long long)r0 | ((unsigned long long)solo_o << 32) | ((unsigned long long)(sidx < total ? RT_SEG : 0) << 40);
             }
-            const unsigned long long v = L.seg[sidx < total ? sidx : 0u];
-            return sidx < total ? v : (v & 0xFF00000000ull);                 // no records
+            return L.seg[sidx < total ? sidx : total];                       // past the end: the empty entry
         };
         auto spheres = [&](unsigned long long e) -> uint4 {
             uint4 v;
@@ -722,17 +729,27 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
         // Candidates in list order: lane by lane, a lane's records in order.  Of a chunk's candidates
         // those at places [from, from + take) are appended (all of them, unless the chunk has more
         // than the ring holds).
-        auto append = [&](const unsigned long long (&m)[RT_LANE_RECS], unsigned long long e0, uint32_t from, uint32_t take) {
-            uint32_t before = 0, mine = 0;
+        auto append = [&](const unsigned long long (&m)[RT_LANE_RECS], const bool (&p)[RT_LANE_RECS], unsigned long long e0) {
+            uint32_t place = produced;
+#pragma unroll
+            for (int r = 0; r < RT_LANE_RECS; r++) place = count_below(m[r], place);
 #pragma unroll
             for (int r = 0; r < RT_LANE_RECS; r++) {
-                before += (uint32_t)__popcll(m[r] & lt);
-                mine |= (uint32_t)((m[r] >> lane) & 1ull) << r;
+                if (p[r]) {
+                    const uint32_t slot = place & (RT_CAND_CAP - 1u);
+                    L.crec[slot] = (uint32_t)e0 + sub + (uint32_t)r; L.cown[slot] = (uint8_t)((uint32_t)(e0 >> 32) & 0xFFu);
+                    place++;
+                }
             }
-            uint32_t place = before;
+        };
+        // the same for the places [from, from + take) of a chunk that has more candidates than the ring takes at once
+        auto append_part = [&](const unsigned long long (&m)[RT_LANE_RECS], unsigned long long e0, uint32_t from, uint32_t take) {
+            uint32_t place = 0;
+#pragma unroll
+            for (int r = 0; r < RT_LANE_RECS; r++) place = count_below(m[r], place);
 #pragma unroll
             for (int r = 0; r < RT_LANE_RECS; r++) {
-                if (mine & (1u << r)) {
+                if ((m[r] >> lane) & 1ull) {
                     if (place - from < take) {
                         const uint32_t slot = (produced + place - from) & (RT_CAND_CAP - 1u);
                         L.crec[slot] = (uint32_t)e0 + sub + (uint32_t)r; L.cown[slot] = (uint8_t)((uint32_t)(e0 >> 32) & 0xFFu);
@@ -748,23 +765,27 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             // that nobody waits for would hold up whoever reuses its register)
             unsigned long long e0 = entry(ch), e1 = entry(ch + 1u), held_m[RT_LANE_RECS], held_e = 0ull;
             uint4 sp0 = spheres(e0), sp1 = sp0;
+            float4 ru0 = rayf[0][wave0 + ((uint32_t)(e0 >> 32) & 0xFFu)], rv0 = rayf[1][wave0 + ((uint32_t)(e0 >> 32) & 0xFFu)];
             bool held = false;
             uint32_t held_n = 0;
             for (; ch < nchunk; ch++) {
                 if (ch + 1u < nchunk) sp1 = spheres(e1);
                 const unsigned long long e2 = entry(ch + 2u);
-                const uint32_t o = (uint32_t)(e0 >> 32) & 0xFFu, cnt = (uint32_t)(e0 >> 40);
-                const float4 a_ = rayf[0][wave0 + o], b_ = rayf[1][wave0 + o];
+                const uint32_t o1 = (uint32_t)(e1 >> 32) & 0xFFu, cnt = (uint32_t)(e0 >> 40);
+                const float4 ru1 = rayf[0][wave0 + o1], rv1 = rayf[1][wave0 + o1];     // the next chunk's ray
+                const float4 a_ = ru0, b_ = rv0;
                 RayF rf;
                 rf.ux = a_.x; rf.uy = a_.y; rf.uz = a_.z; rf.nu = a_.w; rf.vx = b_.x; rf.vy = b_.y; rf.vz = b_.z; rf.nv = b_.w;
                 const uint32_t w[RT_LANE_RECS] = { sp0.x, sp0.y, sp0.z, sp0.w };
                 unsigned long long m[RT_LANE_RECS];
+                bool p[RT_LANE_RECS];
                 uint32_t np = 0;
 #pragma unroll
                 for (int r = 0; r < RT_LANE_RECS; r++) {
                     SphQ q; q.w[0] = w[r];
                     const bool in_seg = sub + (uint32_t)r < cnt, near = sph_pass(q, rf);
-                    m[r] = __ballot(in_seg & near);
+                    p[r] = in_seg & near;
+                    m[r] = ballot64(in_seg) & ballot64(near);                     // two compare masks and a scalar AND
                     np += (uint32_t)__popcll(m[r]);
                 }
 #if RT_STEP_STATS == 7
@@ -777,16 +798,16 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                     ch++;
                     break;
                 }
-                append(m, e0, 0u, np);
+                append(m, p, e0);
                 produced += np;
-                e0 = e1; e1 = e2; sp0 = sp1;
+                e0 = e1; e1 = e2; sp0 = sp1; ru0 = ru1; rv0 = rv1;
             }
             if (held) {
                 // an fp64 pass empties the ring; a chunk with more candidates than the ring holds goes in pieces
                 for (uint32_t from = 0; from < held_n; from += RT_CAND_CAP) {
                     test_all();
                     const uint32_t take = held_n - from < (uint32_t)RT_CAND_CAP ? held_n - from : (uint32_t)RT_CAND_CAP;
-                    append(held_m, held_e, from, take);
+                    append_part(held_m, held_e, from, take);
                     produced += take;
                 }
             }
@@ -837,6 +858,11 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     __shared__ float4 rayf[2][BLOCK];
 #define RT_RAYF_PUT() { const RayF q_ = ray_single(T.d); rayf[0][tid] = make_float4(q_.ux, q_.uy, q_.uz, 0.0f); rayf[1][tid] = make_float4(q_.vx, q_.vy, q_.vz, 0.0f); }
     __shared__ CoopLds coop[BLOCK / 64];      // the wave's candidate list of the cooperative triangle phase
+    // Three blocks of 256 lanes share a CU's 160 KB only while a block asks for no more than 53760
+    // bytes (the allocation is rounded up in steps that 53760 exactly fills): 32 bytes more and a
+    // CU holds two blocks, measured as 9 % (benchmark frame) to 17 % (atrium) more time.
+    static_assert(BLOCK != 256 || sizeof(CoopLds) * (BLOCK / 64) + (sizeof(double) + 2 * sizeof(float4) + 2 * RT_STACK_LEVELS * sizeof(uint32_t)) * BLOCK <= 53760,
+                  "the closest-hit engine's LDS must leave room for three blocks per CU");
     TravState T = {};
     int mode = TM_FETCH;
     // rays are handed to a wave in batches of 64 .. batch_max: a quarter of an even share of what is left
