@@ -541,8 +541,7 @@ struct CoopLds {                 // per wave
     uint32_t crec[RT_CAND_CAP];  // candidate's record index
     uint8_t  cown[RT_CAND_CAP];  // candidate's owner lane
     unsigned long long okey[64]; // per owner lane, per pass: smallest hit distance as an ordered integer
-    uint32_t owin[64];           //   list position + 1 of the last candidate that reached it
-    uint32_t oid[64];            //   that candidate's primitive id
+    unsigned long long owin[64]; //   (list position + 1) << 32 | primitive id of the last candidate that reached it
 };
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 // the lanes for which p holds, as a mask (the predicate's own lane mask: no 0/1 value is formed)
@@ -574,7 +573,6 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
     constexpr uint32_t LANES_PER_SEG = RT_SEG / RT_LANE_RECS, SEGS_PER_CHUNK = 64u / LANES_PER_SEG;
     static_assert(RT_LANE_RECS == 4 && RT_SEG % RT_LANE_RECS == 0, "a lane's spheres are one 16-byte load");
     const uint32_t lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t sub = (lane % LANES_PER_SEG) * RT_LANE_RECS, sseg = lane / LANES_PER_SEG;     // the lane's place in a chunk
     uint32_t produced = 0, tested = 0;                 // candidates appended / tested so far (wave-uniform)
     const bool owner = mode == TM_TRI;
@@ -603,7 +601,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             const uint32_t left = produced - tested, n = left < 64u ? left : 64u;
             const bool act = lane < n;
             const uint32_t slot = (tested + lane) & (RT_CAND_CAP - 1u);
-            L.okey[lane] = ~0ull; L.owin[lane] = 0u;
+            L.okey[lane] = ~0ull; L.owin[lane] = 0ull;
             const uint32_t rec = act ? L.crec[slot] : 0u;
             const int o = act ? (int)L.cown[slot] : (int)lane;
             TriReg R = {};
@@ -645,15 +643,13 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             if (hit) atomicMin(&L.okey[o], key);
             __builtin_amdgcn_wave_barrier();
             const bool best = hit && L.okey[o] == key;
-            if (best) atomicMax(&L.owin[o], tested + lane + 1u);
-            __builtin_amdgcn_wave_barrier();
-            if (best && L.owin[o] == tested + lane + 1u) L.oid[o] = id;
+            if (best) atomicMax(&L.owin[o], ((unsigned long long)(lane + 1u) << 32) | id);      // a pass's candidates are in list order lane by lane
             __builtin_amdgcn_wave_barrier();
             if (owner) {
                 const unsigned long long k = L.okey[lane];
                 if (k != ~0ull) {
                     const double t = ordered_value(k);
-                    if (t <= T.tempt) { T.tempt = t; T.bprim = L.oid[lane]; }      // octree.cpp:30-33
+                    if (t <= T.tempt) { T.tempt = t; T.bprim = (uint32_t)L.owin[lane]; }      // octree.cpp:30-33
                 }
             }
             tested += n;
@@ -665,27 +661,29 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
     };
 
     for (;;) {
-        // ---- step 1: the next job.  An owner with at least a whole chunk of records left takes the
-        // wave for itself (whole chunks of its run need no table: segment s of chunk ch starts at
-        // base + ch * chunk + s * RT_SEG); what is left after that, of all owners, goes through
-        // the segment table.
-        constexpr uint32_t CHUNK_RECS = 64u * RT_LANE_RECS;
+        // ---- step 1: the next job = the segment table of this round.  An owner with at least a whole
+        // chunk of records left takes the wave for itself: its whole chunks are listed by all lanes at
+        // once (segment i starts at base + i * RT_SEG).  Otherwise every owner lists the next segments
+        // of its run, each at its place in a prefix sum over the owners' segment counts.
+        constexpr uint32_t CHUNK_RECS = 64u * RT_LANE_RECS, SOLO_CHUNKS = (RT_SEG_CAP - 1u) / SEGS_PER_CHUNK;
         const uint32_t left = owner ? T.kend - kcur : 0u;
-        const unsigned long long big = __ballot(left >= CHUNK_RECS);
-        bool solo = false;
-        uint32_t solo_o = 0, solo_base = 0, total = 0, nchunk = 0;
+        const unsigned long long big = ballot64(left >= CHUNK_RECS);
+        uint32_t total = 0;
         if (big != 0ull) {
-            solo = true;
-            solo_o = (uint32_t)__ffsll((long long)big) - 1u;
-            solo_base = (uint32_t)__builtin_amdgcn_readlane((int)kcur, (int)solo_o);
-            nchunk = ((uint32_t)__builtin_amdgcn_readlane((int)T.kend, (int)solo_o) - solo_base) / CHUNK_RECS;
-            total = nchunk * SEGS_PER_CHUNK;
-            if (lane == solo_o) kcur += nchunk * CHUNK_RECS;
+            const uint32_t solo_o = (uint32_t)__ffsll((long long)big) - 1u;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)kcur, (int)solo_o);
+            uint32_t nch = ((uint32_t)__builtin_amdgcn_readlane((int)T.kend, (int)solo_o) - base) / CHUNK_RECS;
+            if (nch > SOLO_CHUNKS) nch = SOLO_CHUNKS;
+            total = nch * SEGS_PER_CHUNK;
+#pragma unroll
+            for (uint32_t i = lane; i < SOLO_CHUNKS * SEGS_PER_CHUNK; i += 64u)
+                if (i < total) L.seg[i] = (unsigned long long)(base + i * RT_SEG) | ((unsigned long long)solo_o << 32) | ((unsigned long long)RT_SEG << 40);
+            if (lane == solo_o) kcur += nch * CHUNK_RECS;
         } else {
             uint32_t nseg = (left + (RT_SEG - 1u)) / RT_SEG;
             if (nseg > (uint32_t)RT_SEG_ROUND_MAX) nseg = RT_SEG_ROUND_MAX;
-            const unsigned long long b0 = __ballot(nseg & 1u), b1 = __ballot(nseg & 2u), b2 = __ballot(nseg & 4u), b3 = __ballot(nseg & 8u);
-            uint32_t first = (uint32_t)__popcll(b0 & lt) + 2u * (uint32_t)__popcll(b1 & lt) + 4u * (uint32_t)__popcll(b2 & lt) + 8u * (uint32_t)__popcll(b3 & lt);
+            const unsigned long long b0 = ballot64((nseg & 1u) != 0u), b1 = ballot64((nseg & 2u) != 0u), b2 = ballot64((nseg & 4u) != 0u), b3 = ballot64((nseg & 8u) != 0u);
+            uint32_t first = count_below(b0, 0u) + 2u * count_below(b1, 0u) + 4u * count_below(b2, 0u) + 8u * count_below(b3, 0u);
             total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
             if (total == 0u) break;
             RT_TICK9(rays)
@@ -694,32 +692,28 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             if (nseg > total - first) nseg = total - first;
 #pragma unroll 1
             for (uint32_t j = 0; j < (uint32_t)RT_SEG_ROUND_MAX; j++) {
-                if (!__any(j < nseg)) break;
+                if (ballot64(j < nseg) == 0ull) break;
                 if (j < nseg) {
                     const uint32_t r0 = kcur + j * RT_SEG, cnt = T.kend - r0 < (uint32_t)RT_SEG ? T.kend - r0 : (uint32_t)RT_SEG;
                     L.seg[first + j] = (unsigned long long)r0 | ((unsigned long long)lane << 32) | ((unsigned long long)cnt << 40);
                 }
             }
-            if (lane == 0) L.seg[total] = 0ull;                                     // what a chunk reads past the last segment
             if (nseg) { const uint32_t adv = nseg * RT_SEG; kcur = T.kend - kcur < adv ? T.kend : kcur + adv; }
-            nchunk = (total + SEGS_PER_CHUNK - 1u) / SEGS_PER_CHUNK;
             RT_TICK9(inner)
         }
+        if (lane == 0) L.seg[total] = 0ull;                                         // what a chunk reads past the last segment: no records
+        const uint32_t nchunk = (total + SEGS_PER_CHUNK - 1u) / SEGS_PER_CHUNK;
         // ---- step 2: pre-test chunk by chunk.  A lane takes RT_LANE_RECS consecutive records of its
         // segment (one 16-byte load brings their spheres, one LDS read the owner's ray).  A chunk's
-        // segment entry is read from LDS three chunks and its spheres are requested two chunks ahead
-        // of their use, unconditionally (past the last segment: entry 0 with no records), so that
-        // the wait in front of a chunk's tests leaves the younger loads in flight.  Nothing else is
-        // loaded inside the loop: when the candidate ring cannot take a chunk's candidates the loop
-        // is left, the ring emptied by an fp64 pass, and the loop entered again.
+        // segment entry is read from LDS two chunks ahead, its spheres and its owner's ray are
+        // requested one chunk ahead of their use, unconditionally (past the last segment: the empty
+        // entry), so that nothing a chunk's tests wait for was requested in the same iteration.
+        // Nothing else is loaded inside the loop: when the candidate ring cannot take a chunk's
+        // candidates the loop is left, the ring emptied by an fp64 pass, and the loop entered again.
         RT_TICK8(rays)
         auto entry = [&](uint32_t ch) -> unsigned long long {
             const uint32_t sidx = ch * SEGS_PER_CHUNK + sseg;
-            if (solo) {
-                const uint32_t r0 = sidx < total ? solo_base + sidx * RT_SEG : 0u;
-                return (unsigned long long)r0 | ((unsigned long long)solo_o << 32) | ((unsigned long long)(sidx < total ? RT_SEG : 0) << 40);
-            }
-            return L.seg[sidx < total ? sidx : total];                       // past the end: the empty entry
+            return L.seg[sidx < total ? sidx : total];
         };
         auto spheres = [&](unsigned long long e) -> uint4 {
             uint4 v;
