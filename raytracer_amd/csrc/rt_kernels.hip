@@ -510,17 +510,19 @@ __device__ __forceinline__ bool sph_pass(const SphQ &q, const RayF &r)
 // done by the whole wave at once instead of by each lane for itself:
 //   1. segments: every owner cuts its run into segments of RT_SEG records and lists them in the
 //      wave's segment table in LDS (a prefix sum over the owners' segment counts gives each its
-//      place), so that the work of all owners lies in one dense list;
-//   2. pre-test: a chunk = 64 / RT_SEG consecutive segments; every lane takes ONE record of its
-//      segment, tests the record's sphere against the segment owner's ray (read from LDS, where the
-//      owner left it when the run opened) and the lanes whose record passes append (record, owner)
-//      to the wave's candidate list in LDS (ballot + popcount);
+//      place), so that the work of all owners lies in one dense list; a run with a whole chunk of
+//      records or more left gets the table to itself, filled by all lanes at once;
+//   2. pre-test: a chunk = 64 * RT_LANE_RECS / RT_SEG consecutive segments; every lane takes
+//      RT_LANE_RECS consecutive records of its segment, tests their spheres against the segment
+//      owner's ray (read from LDS, where the owner left it when the run opened) and appends
+//      (record, owner) for those that pass to the wave's candidate list in LDS (ballot + count of
+//      the set bits below the lane);
 //   3. test: every lane takes one candidate, fetches its 80-byte record and the owner's fp64 ray
 //      and window (cross-lane reads) and makes the fp64 primitive test -- up to 64 candidates of
 //      different owners per pass;
 //   4. per owner the pass keeps the smallest hit distance (an LDS minimum over order-preserving
 //      integer keys) and, among the candidates that reached it, the last one in list order (an LDS
-//      maximum over list positions): OctreeNode::hit accepts a hit with `t <= tempt`, so of equal
+//      maximum over list position | id): OctreeNode::hit accepts a hit with `t <= tempt`, so of equal
 //      distances the later primitive wins (octree.cpp:31), and a hit farther than an earlier one
 //      never survives -- the same outcome as testing the owner's candidates one after the other.
 // The wave's cost follows the number of records it serves, not its longest run, and the fp64 tests
