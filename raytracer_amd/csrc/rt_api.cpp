@@ -316,6 +316,74 @@ static SphereD triangle_sphere(const LeafTri &t)
     return s;
 }
 
+// The sphere for a triangle record of node n: around the part of the triangle that lies inside the
+// node's box.  A primitive test only accepts a hit inside the node's window, the stretch of the ray
+// inside the box (octree.cpp:19-38 with the window of algorithms.h:223-236), so the rest of the
+// triangle cannot be hit from this run, and a triangle much larger than the node (a wall crossing
+// many leaves) gets a sphere of the node's size instead of its own.  The box is grown by 1/64 of its
+// longest edge on every side first: the window's ends are rounded distances, and the hit point of
+// a distance inside the window may lie outside the box by that rounding (of the order of 1e-16 of
+// the distance the ray has travelled; 1/64 of the node's edge is beyond that for any ray that
+// double precision can place in the node at all).  Clipping is Sutherland-Hodgman against the six
+// planes; the sphere is centred on the middle of the clipped polygon's bounds and reaches its
+// farthest corner.  The triangle's own sphere is kept when it is the smaller one; a triangle that
+// misses the grown box gets an empty sphere at the box's corner.
+static SphereD clipped_triangle_sphere(const LeafTri &t, const FlatNode &n)
+{
+    const SphereD whole = triangle_sphere(t);
+    double ext = 0;
+    for (int k = 0; k < 3; k++) { const double e = n.hi[k] - n.lo[k]; if (!(e <= ext)) ext = e; }
+    if (!whole.ok || !std::isfinite(ext) || !(ext > 0)) return whole;
+    const double grow = ext / 64;
+    double poly[2][16][3];
+    int cnt = 3, cur = 0;
+    for (int k = 0; k < 3; k++) { poly[0][0][k] = t.v0[k]; poly[0][1][k] = t.v0[k] + t.e1[k]; poly[0][2][k] = t.v0[k] + t.e2[k]; }
+    for (int k = 0; k < 3 && cnt; k++) {
+        for (int side = 0; side < 2 && cnt; side++) {
+            const double plane = side ? n.hi[k] + grow : n.lo[k] - grow;
+            const double sgn = side ? -1.0 : 1.0;                 // inside: sgn * (x - plane) >= 0
+            double (*in)[3] = poly[cur], (*out)[3] = poly[cur ^ 1];
+            int m = 0;
+            for (int i = 0; i < cnt; i++) {
+                const double *a = in[i], *b = in[(i + 1) % cnt];
+                const double da = sgn * (a[k] - plane), db = sgn * (b[k] - plane);
+                if (!std::isfinite(da) || !std::isfinite(db)) return whole;
+                if (da >= 0) { for (int c = 0; c < 3; c++) out[m][c] = a[c]; m++; }
+                if ((da >= 0) != (db >= 0)) {
+                    const double u = da / (da - db);
+                    for (int c = 0; c < 3; c++) out[m][c] = a[c] + (b[c] - a[c]) * u;
+                    out[m][k] = plane;
+                    m++;
+                }
+                if (m > 14) return whole;                         // cannot happen: a triangle cut by six planes has at most nine corners
+            }
+            cnt = m; cur ^= 1;
+        }
+    }
+    SphereD s;
+    s.ok = true;
+    if (cnt == 0) {
+        for (int k = 0; k < 3; k++) s.c[k] = n.lo[k];
+        s.r = 0;
+        return s;
+    }
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) { lo[k] = hi[k] = poly[cur][0][k]; }
+    for (int i = 1; i < cnt; i++)
+        for (int k = 0; k < 3; k++) { if (poly[cur][i][k] < lo[k]) lo[k] = poly[cur][i][k]; if (poly[cur][i][k] > hi[k]) hi[k] = poly[cur][i][k]; }
+    double r2 = 0;
+    for (int k = 0; k < 3; k++) s.c[k] = (lo[k] + hi[k]) / 2;
+    for (int i = 0; i < cnt; i++) {
+        double d2 = 0;
+        for (int k = 0; k < 3; k++) d2 += (poly[cur][i][k] - s.c[k]) * (poly[cur][i][k] - s.c[k]);
+        if (!(d2 <= r2)) r2 = d2;
+    }
+    s.r = std::sqrt(r2) * (1.0 + 1e-9);                           // the cut points are rounded
+    s.ok = std::isfinite(s.c[0]) && std::isfinite(s.c[1]) && std::isfinite(s.c[2]) && std::isfinite(s.r);
+    if (!s.ok || whole.r <= s.r) return whole;
+    return s;
+}
+
 // A sphere that holds the whole node in the node's grid (the box reaches at most RT_SPH_EDGE units
 // along every axis from RT_SPH_ORG, so its corners are within 0.9 RT_SPH_EDGE of RT_SPH_MID and the
 // largest radius is two edges): the pre-test passes
@@ -544,7 +612,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         std::memcpy(&bits, &scale, 4);
         n.pad = bits | (n.pad & 1u);                  // grid scale, voxel flag in the lowest bit
         for (uint32_t i = n.obj_begin; i < n.obj_begin + n.obj_count; i++)
-            pack_sphere(&leaf_sph[(size_t)i * RT_SPH_WORDS], (leaf_tris[i].id & LEAF_VOXEL) ? voxel_sphere(leaf_tris[i]) : triangle_sphere(leaf_tris[i]), n, scale);
+            pack_sphere(&leaf_sph[(size_t)i * RT_SPH_WORDS], (leaf_tris[i].id & LEAF_VOXEL) ? voxel_sphere(leaf_tris[i]) : clipped_triangle_sphere(leaf_tris[i], n), n, scale);
     }
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
     void *p_pp = nullptr, *p_pg = nullptr;
