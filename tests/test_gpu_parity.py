@@ -122,12 +122,14 @@ def test_trace_rays_bit_exact_vs_oracle(seed, ntri, max_size, edge):
         assert np.array_equal(c1, c2)         # rays, inner visits, leaf visits, primitive tests
 
 
-@pytest.mark.parametrize("case", ["far", "slivers", "flat", "mixed_sizes"])
+@pytest.mark.parametrize("case", ["far", "slivers", "flat", "mixed_sizes", "on_split_planes"])
 def test_sphere_pretest_never_rejects_a_hit(case):
     """The single-precision sphere pre-test works in a per-node integer grid; geometry that is hard
     on it must still give the oracle's ids, distances and test counts bit for bit: a mesh far from
     the origin (coordinates 1e8 times the triangle size), needle triangles, a mesh with no extent
-    along one axis, and triangles from 1e-4 to 1 of the mesh's size in one octree."""
+    along one axis, triangles from 1e-4 to 1 of the mesh's size in one octree, and walls across the
+    whole mesh that lie exactly in the octree's splitting planes (a record's sphere bounds the part
+    of its triangle inside the node's box: here that part is a face of the box)."""
     rng = np.random.default_rng(91)
     if case == "far":
         tris = scenes.soup(8000, seed=91, edge_lo=1e-3, edge_hi=1e-2)
@@ -142,9 +144,21 @@ def test_sphere_pretest_never_rejects_a_hit(case):
         tris = scenes.soup(5000, seed=93, edge_lo=5e-3, edge_hi=5e-2)
         tris[:, 1::3] = 0.25                                   # every vertex at y = 0.25
         lo, hi = np.full(3, -0.5), np.full(3, 1.5)
-    else:
+    elif case == "mixed_sizes":
         tris = np.concatenate([scenes.soup(5000, seed=94, edge_lo=1e-4, edge_hi=1e-3), scenes.soup(300, seed=95, edge_lo=0.3, edge_hi=1.0)])
         lo, hi = np.full(3, -0.5), np.full(3, 1.5)
+    else:
+        walls = []
+        for axis, c in ((0, 0.5), (1, 0.25), (2, 0.75), (0, 0.125), (1, 0.5), (2, 0.5), (0, 0.0), (0, 1.0), (1, 0.0), (1, 1.0), (2, 0.0), (2, 1.0)):
+            a, b = [k for k in range(3) if k != axis]
+            q = np.zeros((4, 3))
+            q[:, axis] = c
+            q[:, a] = (0, 1, 1, 0)
+            q[:, b] = (0, 0, 1, 1)
+            walls += [np.concatenate([q[0], q[1], q[2]]), np.concatenate([q[0], q[2], q[3]])]
+        pebbles = np.clip(scenes.soup(6000, seed=96, edge_lo=2e-3, edge_hi=2e-2), 0.0, 1.0)       # the mesh's bounds are the unit cube: splits at k / 2^d
+        tris = np.concatenate([np.array(walls), pebbles])
+        lo, hi = np.full(3, -0.25), np.full(3, 1.25)
     desc = _mesh_desc(np.ascontiguousarray(tris), octree_max_size=16, octree_max_depth=15)
     so, sg = orc.OracleScene(desc), hip.HipScene(desc)
     assert so.octree_stats(0) == sg.octree_stats(0)
