@@ -251,10 +251,6 @@ struct Hit { double t; int32_t obj; uint32_t prim; };
 #ifndef RT_BATCH0
 #define RT_BATCH0 1024
 #endif
-// records whose spheres one triangle step tests
-#ifndef RT_PRE
-#define RT_PRE 16
-#endif
 #ifndef RT_WT
 #define RT_WT 24
 #endif
