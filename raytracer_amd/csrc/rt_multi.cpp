@@ -46,7 +46,11 @@ const Rccl *rccl(std::string &why)
         const char *names[] = {"librccl.so.1", "librccl.so"};
         for (const char *n : names) if (!R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // one that is loaded already
         for (const char *n : names) if (!R.lib) R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (!R.lib) { R.err = std::string("RCCL is not loadable: ") + (dlerror() ? dlerror() : "librccl.so.1 not found"); return; }
+        if (!R.lib) {
+            const char *why = dlerror();                  // a second call would return null: the first one clears it
+            R.err = std::string("RCCL is not loadable: ") + (why ? why : "librccl.so.1 not found");
+            return;
+        }
         auto sym = [&](const char *name) { void *p = dlsym(R.lib, name); if (!p && R.err.empty()) R.err = std::string("RCCL lacks ") + name; return p; };
         R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
         R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
@@ -247,9 +251,9 @@ int rt_multi_render(rt_multi *M, const rt_camera *cam, const rt_render_params *p
     const int total = params->sample_end - params->sample_begin, spp = params->n * params->m;
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
-    // one host thread per device: buffers, this member's slice of the sample indices (contiguous,
-    // balanced), and -- with RCCL -- the reduce, which every member must enter
-    auto work = [&](int i) {
+    // One host thread per device, in two rounds.  First the buffers: a member that cannot get its
+    // buffers must be known before anybody enters the collective, which it could not join.
+    auto prepare = [&](int i) {
         rt_multi::Member &q = M->m[i];
         auto done = [&](int rc) { rcs[i] = rc; if (rc) errs[i] = rt_last_error(); };
         if (int rc = rt_set_device(q.device)) return done(rc);
@@ -257,11 +261,27 @@ int rt_multi_render(rt_multi *M, const rt_camera *cam, const rt_render_params *p
         hipError_t e = hipMemsetAsync(q.sum, 0, pixels * 3 * sizeof(double), nullptr);
         if (e == hipSuccess) e = hipMemsetAsync(q.counters, 0, 32, nullptr);
         if (e != hipSuccess) return done(rt::set_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e), -2));
+        done(0);
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int i = 1; i < n; i++) threads.emplace_back(prepare, i);
+        prepare(0);
+        for (auto &t : threads) t.join();
+        for (int i = 0; i < n; i++) if (rcs[i]) return rt::set_error(errs[i], rcs[i]);
+    }
+    // Then this member's slice of the sample indices (contiguous, balanced) and -- with RCCL -- the
+    // reduce, which every member enters.
+    auto work = [&](int i) {
+        rt_multi::Member &q = M->m[i];
+        auto done = [&](int rc) { rcs[i] = rc; if (rc) errs[i] = rt_last_error(); };
+        int rc0 = rt_set_device(q.device);
+        hipError_t e = hipSuccess;
         rt_render_params p = *params;
         const int base = total / n, rem = total % n;
         p.sample_begin = params->sample_begin + i * base + (i < rem ? i : rem);
         p.sample_end = p.sample_begin + base + (i < rem ? 1 : 0);
-        int rc = rt_render(q.scene, cam, &p, q.sum, q.counters, nullptr);
+        int rc = rc0 ? rc0 : rt_render(q.scene, cam, &p, q.sum, q.counters, nullptr);
         if (rc == 0) rc = rt_scene_check(q.scene, nullptr);
         // a member that failed still enters the reduce (its partial buffer is discarded with the frame):
         // leaving the others waiting in the collective would hang them
