@@ -170,3 +170,31 @@ def test_render_with_rectangular_jitter_table(n, m):
     if n != m:
         i3, _ = sg.render(c, render_params(W, H, m, n, seed=77))
         assert np.abs(i3 - i2).max() > 1e-6
+
+
+def test_workspace_limit_changes_round_size_only():
+    """rt_scene_set_workspace_limit: the pending-ray stacks stay under the limit (down to the
+    smallest round of 64 Ki rays), the frame and its work counters do not change (only the order of
+    the additions into a pixel does), and the ray-flow counts add up: every ray traced for a hit was
+    a camera ray or an appended bounce ray, every other traced ray an appended shadow ray."""
+    desc, cam = scenes.bunny_cornell_scene(nu=40, nv=41)
+    c = hip.camera_init(**cam)
+    prm = render_params(256, 256, 2, seed=5)
+    free = hip.HipScene(desc)
+    img_a, cnt_a = free.render(c, prm)
+    small = hip.HipScene(desc)
+    small.set_workspace_limit(256 << 20)
+    img_b, cnt_b = small.render(c, prm)
+    assert 0 < small.workspace_bytes() <= (256 << 20) < free.workspace_bytes()
+    assert np.array_equal(cnt_a, cnt_b)
+    assert _rel(img_a, img_b).max() < 1e-9
+    flow = small.get_ray_flow()
+    assert flow["first_rays"] == 256 * 256 * 4
+    assert flow["shaded_in"] == flow["first_rays"] + flow["bounce_class0"] + flow["bounce_class1"]
+    shadows = flow["shadow_class0"] + flow["shadow_class1"]
+    cut = flow["shaded_in"] + shadows - float(cnt_b[0])          # rays past the depth limit are handed to shading untraced
+    assert shadows > 0 and 0 <= cut <= 1e-3 * float(cnt_b[0])
+    # back to the default policy: the larger workspace is kept, results as before
+    small.set_workspace_limit(0)
+    img_c, cnt_c = small.render(c, prm)
+    assert np.array_equal(cnt_a, cnt_c) and _rel(img_a, img_c).max() < 1e-9
