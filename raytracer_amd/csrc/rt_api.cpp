@@ -60,7 +60,7 @@ struct rt_scene {
     void *ws_mem = nullptr;
     uint64_t ws_bytes = 0;
     uint64_t ws_limit = 0;        // rt_scene_set_workspace_limit (0 = the default policy)
-    uint32_t *d_ctrl = nullptr;   // [0..3] rays appended per destination by the running kernel; [4] the path tracer's ray hand-out counter; [5] the closest-hit entry points' one
+    uint32_t *d_ctrl = nullptr;   // [0..3] rays appended per destination by the running kernel; [4] the path tracer's ray hand-out counter; [5] the length of its retry list; [6] the closest-hit entry points' hand-out counter
     uint32_t *h_ctrl = nullptr;   // pinned mirror of d_ctrl[0..3]
     int failed = 0;               // a render ran out of ray-stack space
     // optional stage timing
@@ -732,7 +732,7 @@ int rt_trace_rays(rt_scene *s, const rt_ray *rays, uint64_t n, double t0, double
     if (n && (!rays || !prim_id)) return fail("rt_trace_rays: null buffer");
     if (n >= 0xFFFFFFFFull) return fail("rt_trace_rays: batch too large");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 5, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_rays(s->dev, s->num_cu, s->d_ctrl + 6, rays, n, t0, t1, prim_id, t, normal, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -742,7 +742,7 @@ int rt_trace_primary(rt_scene *s, const rt_camera *cam, int w, int h, uint32_t *
     if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || (uint64_t)w * (uint64_t)h >= 0xFFFF0000ull) return fail("rt_trace_primary: bad image size");
     if (!prim_id) return fail("rt_trace_primary: null buffer");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 5, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
+    HIP_TRY(launch_trace_primary(s->dev, s->num_cu, s->d_ctrl + 6, *cam, w, h, prim_id, t, counters, (hipStream_t)stream));
     return 0;
 }
 
@@ -772,6 +772,7 @@ static uint64_t env_u64(const char *name, uint64_t dflt)
 struct WaveSpace {
     RayStack stack[2][2];
     ShadowStack sstack[2];
+    uint32_t *retry;            // scap ray indices: the retry list of one launch (see launch_trace)
     uint32_t *d_ctrl;
     uint64_t cap, scap, target;
 };
@@ -781,7 +782,7 @@ static uint64_t radiance_stack_bytes(uint64_t cap) { return round256(cap * (RAY_
 static uint64_t shadow_stack_bytes(uint64_t scap) { return round256(scap * SH_FIELDS * sizeof(uint64_t)) + round256(scap * sizeof(uint32_t)); }
 static uint64_t workspace_bytes(uint64_t target, uint64_t P, uint64_t L)
 {
-    return 4 * radiance_stack_bytes(target * (P + 3)) + 2 * shadow_stack_bytes(target * (L + 1));
+    return 4 * radiance_stack_bytes(target * (P + 3)) + 2 * shadow_stack_bytes(target * (L + 1)) + round256(target * (L + 1) * sizeof(uint32_t));
 }
 // Lays the six stacks for `target` rays per round out in memory at `base` (256-byte aligned).
 static void carve_workspace(void *base, uint64_t target, uint64_t P, uint64_t L, WaveSpace &ws)
@@ -803,6 +804,7 @@ static void carve_workspace(void *base, uint64_t target, uint64_t P, uint64_t L,
         ws.sstack[c].cap = ws.scap;
         p += shadow_stack_bytes(ws.scap);
     }
+    ws.retry = (uint32_t *)p;       // a launch traces at most target bounce rays or scap shadow rays
 }
 
 // One allocation of at least `bytes`, or none: a failed allocation leaves the scene without a workspace.
@@ -838,7 +840,7 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
     auto drain = [&](int cls) -> int {
         if (!scount[cls]) return 0;
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[3], st));
-        HIP_TRY(launch_trace_shadow(s->dev, s->num_cu, d_ctrl + 4, A, ws.sstack[cls], 0, (uint32_t)scount[cls], cls, st));
+        HIP_TRY(launch_trace_shadow(s->dev, s->num_cu, d_ctrl, ws.retry, A, ws.sstack[cls], 0, (uint32_t)scount[cls], cls, st));
         if (s->profiling) {
             float a = 0;
             HIP_TRY(hipEventRecord(s->ev[4], st));
@@ -891,7 +893,7 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
         D.count = d_ctrl;
         HIP_TRY(hipMemsetAsync(d_ctrl, 0, 16, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
-        HIP_TRY(launch_trace(s->dev, s->num_cu, d_ctrl + 4, A, ws.stack[X][cur[X]], base, (uint32_t)c, X, st));
+        HIP_TRY(launch_trace(s->dev, s->num_cu, d_ctrl, ws.retry, A, ws.stack[X][cur[X]], base, (uint32_t)c, X, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
         HIP_TRY(launch_shade(s->dev, A, ws.stack[X][cur[X]], base, (uint32_t)c, D, st));
         if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));

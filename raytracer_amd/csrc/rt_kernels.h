@@ -14,11 +14,13 @@ hipError_t launch_trace_primary(const DevScene &S, int num_cu, uint32_t *next, c
                                 double *t, uint64_t *counters, hipStream_t st);
 // wavefront path-tracing stages (see rt_device.h)
 hipError_t launch_generate(const DevScene &S, const WaveArgs &A, const RayDest &dst, uint64_t first, uint32_t count, hipStream_t st);
-// ray_class: the class of the chunk's rays (see RayDest)
-hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
+// ray_class: the class of the chunk's rays (see RayDest).  `ctrl` = the scene's control words ([4] and
+// [5] are zeroed and used); `retry` = room for `count` ray indices: class-0 rays that reach an octree
+// after all are listed there and traced again by the engine.
+hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *ctrl, uint32_t *retry, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
                         int ray_class, hipStream_t st);
 // the shadow test of a chunk of a shadow stack; unblocked rays add their radiance to A.out
-hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const ShadowStack &q, uint64_t base,
+hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *ctrl, uint32_t *retry, const WaveArgs &A, const ShadowStack &q, uint64_t base,
                                uint32_t count, int ray_class, hipStream_t st);
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
                         const RayDest &dst, hipStream_t st);

@@ -1602,6 +1602,135 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, ui
     flush_counters(src.A.counters, c);
 }
 
+// ------------------------------------------------------------------ rays that stay outside the octrees
+// Rays of class 0 (see RayDest) are expected to miss the root box of every octree with inner
+// nodes, so their whole search is one walk over the object table: Group::hit (Surface.cpp:160-181)
+// with spheres, planes and one-leaf meshes answered on the spot.  Such rays need none of the
+// closest-hit engine's machinery -- no node stack, no phases, no hand-out of rays to free lanes --
+// and a plain kernel serves them: one ray per lane from start to end, every lane at the same
+// object at the same time, registers and LDS for far more waves per SIMD.
+// The class is a single-precision guess, though.  A ray that does reach an octree's root box here
+// (the same double-precision slab test that the engine's first node step makes) is not answered:
+// its index goes to the launch's retry list, nothing is counted or stored for it, and the engine
+// traces the rays of that list from scratch right after this kernel (RetrySrc), so every ray gets
+// the result and the work counters that the engine alone would have produced.
+template <class Src>
+__device__ __forceinline__ void sweep_rays(const DevScene &S, const Src &src, uint32_t *retry_count, uint32_t *retry_list, Counters &c)
+{
+    const uint32_t total = src.count();
+    const uint32_t lane = threadIdx.x & 63u;
+    const u_object objects = (u_object)(unsigned long long)S.objects;
+    for (uint32_t first = blockIdx.x * RT_BLOCK; first < total; first += gridDim.x * RT_BLOCK) {
+        const uint32_t item = first + threadIdx.x;
+        V3 e = mk(0, 0, 0), d = mk(0, 0, 1);
+        double t0 = 0, t1 = 0;
+        bool live = false;
+        if (item < total) {
+            live = src.load(item, e, d, t0, t1);
+            if (!live) { Hit h; h.t = RT_INFINITE; h.obj = -1; h.prim = 0; src.store(item, false, h); }
+        }
+        const bool fast = S.regular && dir_is_regular(d) && org_is_regular(e);
+        const V3 r = fast ? mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z) : mk(0, 0, 0);
+        int32_t hobj = -1;
+        uint32_t hprim = 0, nleaf = 0, nprim = 0;
+        bool defer = false;
+        for (int o = 0; o < S.nobjects; o++) {
+            const bool mine = live && !defer;
+            if (ballot64(mine) == 0ull) break;
+            const int otype = objects[o].type;
+            if (otype == RT_OBJ_MESH) {
+                const uint32_t ntri = objects[o].ntri;
+                const V3 lo = mk(objects[o].lo[0], objects[o].lo[1], objects[o].lo[2]), hi = mk(objects[o].hi[0], objects[o].hi[1], objects[o].hi[2]);
+                double n0 = 0, n1 = 0;
+                const bool hb = mine && (fast ? hit_box_fast(lo, hi, e, d, r, t0, t1, n0, n1) : hit_box(lo, hi, e, d, t0, t1, n0, n1));
+                if (!ntri) { if (hb) defer = true; continue; }          // an octree with inner nodes: Octree::hit's root test (octree.cpp:291)
+                // a one-leaf octree: the root's slab test and OctreeNode::hit on it (octree.cpp:285-376, 19-38)
+                double tempt = n1;
+                uint32_t bprim = RT_MISS;
+                if (hb) { nleaf++; nprim += ntri; }
+                if (ballot64(hb) != 0ull) {
+                    const u_leaftri P = (u_leaftri)(unsigned long long)(S.leaf_tris + objects[o].leaf_begin);
+                    TriReg tr_next = tri_load_uniform(P);
+#pragma unroll 1
+                    for (uint32_t k = 0; k < ntri; k++) {
+                        const TriReg tr = tr_next;
+                        tr_next = tri_load_uniform(P + (k + 1 < ntri ? k + 1 : k));
+                        double tt;
+                        if (hb && tri_hit(tr, e, d, n0, tempt, tt)) { tempt = tt; bprim = tr.id; }      // last equal wins, octree.cpp:31
+                    }
+                    if (hb && bprim != RT_MISS && tempt < t1 + 1 && tempt <= t1) { t1 = tempt; hobj = o; hprim = bprim; }    // octree.cpp:313, 320-325, 371-375
+                }
+            } else if (otype == RT_OBJ_HEART || otype == RT_OBJ_GENUS2) {
+                // HeartShape::hit (Surface.cpp:268-276), ImplicitSurface::hit (Surface.h:308-316): the
+                // voxel tree's root test with the ray in the surface's frame
+                if (mine) {
+                    const double inv = 1.0 / objects[o].p[3];
+                    const V3 le = (e - mk(objects[o].p[0], objects[o].p[1], objects[o].p[2])) * inv, ld = d * inv;
+                    const FlatNode *rn = S.nodes + objects[o].root;
+                    const V3 lo = mk(rn->lo[0], rn->lo[1], rn->lo[2]), hi = mk(rn->hi[0], rn->hi[1], rn->hi[2]);
+                    const bool lfast = S.regular && dir_is_regular(ld) && org_is_regular(le);
+                    double n0, n1;
+                    if (lfast ? hit_box_fast(lo, hi, le, ld, mk(1.0 / ld.x, 1.0 / ld.y, 1.0 / ld.z), t0, t1, n0, n1) : hit_box(lo, hi, le, ld, t0, t1, n0, n1)) defer = true;
+                }
+            } else if (mine) {
+                const double p0 = objects[o].p[0], p1 = objects[o].p[1], p2 = objects[o].p[2], p3 = objects[o].p[3];
+                double t;
+                const bool hit = (otype == RT_OBJ_SPHERE) ? sphere_hit(mk(p0, p1, p2), p3, e, d, t0, t1, t) : plane_hit(otype, p0, e, d, t0, t1, t);
+                if (hit) { t1 = t; hobj = o; hprim = 0; }
+            }
+        }
+        if (live && !defer) {
+            Hit h; h.t = t1; h.obj = hobj; h.prim = hprim;
+            src.store(item, hobj >= 0, h);
+            c.rays++; c.leaf += nleaf; c.prim += nprim;
+        }
+        const unsigned long long dm = ballot64(defer);
+        if (dm != 0ull) {
+            uint32_t at = 0;
+            if (lane == (uint32_t)__ffsll((long long)dm) - 1u) at = atomicAdd(retry_count, (uint32_t)__popcll(dm));
+            at = (uint32_t)__builtin_amdgcn_readlane((int)at, __ffsll((long long)dm) - 1);
+            if (defer) retry_list[at + count_below(dm, 0u)] = item;
+        }
+    }
+}
+// The rays of a retry list through the closest-hit engine: item i of the launch is ray list[i] of `b`.
+template <class Base>
+struct RetrySrc {
+    Base b; const uint32_t *list; const uint32_t *n;
+    __device__ uint32_t count() const { return *n; }
+    __device__ bool load(uint32_t i, V3 &e, V3 &d, double &t0, double &t1) const { return b.load(list[i], e, d, t0, t1); }
+    __device__ void reload(uint32_t i, V3 &e, V3 &d) const { b.reload(list[i], e, d); }
+    __device__ void store(uint32_t i, bool hit, const Hit &h) const { b.store(list[i], hit, h); }
+};
+__global__ __launch_bounds__(RT_BLOCK) void k_sweep(DevScene S, StackSrc src, uint32_t *retry_count, uint32_t *retry_list)
+{
+    Counters c = { 0, 0, 0, 0 };
+    sweep_rays(S, src, retry_count, retry_list, c);
+    flush_counters(src.A.counters, c);
+}
+__global__ __launch_bounds__(RT_BLOCK) void k_sweep_shadow(DevScene S, ShadowSrc src, uint32_t *retry_count, uint32_t *retry_list, uint64_t *counters)
+{
+    Counters c = { 0, 0, 0, 0 };
+    sweep_rays(S, src, retry_count, retry_list, c);
+    flush_counters(counters, c);
+}
+RT_TRACE_ATTR
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_retry(DevScene S, RetrySrc<StackSrc> src, uint32_t *next, uint32_t batch_max)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    Counters c = { 0, 0, 0, 0 };
+    trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
+    flush_counters(src.b.A.counters, c);
+}
+RT_TRACE_ATTR
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow_retry(DevScene S, RetrySrc<ShadowSrc> src, uint32_t *next, uint32_t batch_max, uint64_t *counters)
+{
+    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    Counters c = { 0, 0, 0, 0 };
+    trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
+    flush_counters(counters, c);
+}
+
 // Consume the hits of chunk [base, base+count) of `src`; follow-up rays are appended to D.
 // KINDS says which material features the scene's objects use (DevScene::shade_kinds): 1 = a mirror
 // lobe, 2 = a dielectric lobe, 4 = the Phong / Whitted branch (materials without MONTECARLO, Perlin
@@ -1860,14 +1989,14 @@ __global__ void k_resolve_bgr8(const double *sum, uint64_t npix, double inv, int
 // Persistent grids: no more blocks than stay resident, no more than the rays need.
 static unsigned engine_blocks(uint64_t items, int num_cu, const void *kernel)
 {
-    static thread_local const void *cached_k[4] = { nullptr, nullptr, nullptr, nullptr };
-    static thread_local int cached_v[4] = { 0, 0, 0, 0 };
+    static thread_local const void *cached_k[8] = {};
+    static thread_local int cached_v[8] = {};
     int per_cu = 0;
-    for (int i = 0; i < 4; i++) if (cached_k[i] == kernel) per_cu = cached_v[i];
+    for (int i = 0; i < 8; i++) if (cached_k[i] == kernel) per_cu = cached_v[i];
     if (!per_cu) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RT_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        for (int i = 0; i < 4; i++) if (!cached_k[i]) { cached_k[i] = kernel; cached_v[i] = per_cu; break; }
+        for (int i = 0; i < 8; i++) if (!cached_k[i]) { cached_k[i] = kernel; cached_v[i] = per_cu; break; }
     }
     uint64_t resident = (uint64_t)(num_cu > 0 ? num_cu : 256) * (uint64_t)per_cu;
     uint64_t need = (items + RT_BLOCK - 1) / RT_BLOCK;
@@ -1899,25 +2028,47 @@ hipError_t launch_generate(const DevScene &S, const WaveArgs &A, const RayDest &
     hipLaunchKernelGGL(k_generate, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A, dst, first, count);
     return hipGetLastError();
 }
-hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
+// grid of a sweep kernel: enough blocks to fill the device a few times over, each striding over the rays
+static unsigned sweep_blocks(uint64_t items, int num_cu)
+{
+    const uint64_t need = (items + RT_BLOCK - 1) / RT_BLOCK, most = (uint64_t)(num_cu > 0 ? num_cu : 256) * 16u;
+    return (unsigned)(need < most ? need : most);
+}
+// `ctrl` = the scene's control words: [4] the engine's ray hand-out counter, [5] the length of the
+// retry list (both zeroed here); `retry` = room for `count` ray indices.
+hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *ctrl, uint32_t *retry, const WaveArgs &A, const RayStack &q, uint64_t base, uint32_t count,
                         int ray_class, hipStream_t st)
 {
     if (!count) return hipSuccess;
     StackSrc src = { A, q, base, count };
-    hipError_t e = hipMemsetAsync(next, 0, 4, st);
+    hipError_t e = hipMemsetAsync(ctrl + 4, 0, 8, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, next, ray_class ? (uint32_t)RT_BATCH1 : (uint32_t)RT_BATCH0);
+    if (ray_class == 0) {
+        // the object walk for all, then the engine for the few that reached an octree after all
+        RetrySrc<StackSrc> again = { src, retry, ctrl + 5 };
+        hipLaunchKernelGGL(k_sweep, dim3(sweep_blocks(count, num_cu)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 5, retry);
+        hipLaunchKernelGGL(k_trace_retry, dim3(engine_blocks(count, num_cu, (const void *)k_trace_retry)), dim3(RT_BLOCK), 0, st, S, again, ctrl + 4, (uint32_t)RT_BATCH1);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4, (uint32_t)RT_BATCH1);
     return hipGetLastError();
 }
-hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *next, const WaveArgs &A, const ShadowStack &q, uint64_t base,
+hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *ctrl, uint32_t *retry, const WaveArgs &A, const ShadowStack &q, uint64_t base,
                                uint32_t count, int ray_class, hipStream_t st)
 {
     if (!count) return hipSuccess;
     ShadowSrc src = { q, base, count, A.out };
-    hipError_t e = hipMemsetAsync(next, 0, 4, st);
+    hipError_t e = hipMemsetAsync(ctrl + 4, 0, 8, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_shadow, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow)), dim3(RT_BLOCK), 0, st, S, src, next,
-                       ray_class ? (uint32_t)RT_BATCH1 : (uint32_t)RT_BATCH0, A.counters);
+    if (ray_class == 0) {
+        RetrySrc<ShadowSrc> again = { src, retry, ctrl + 5 };
+        hipLaunchKernelGGL(k_sweep_shadow, dim3(sweep_blocks(count, num_cu)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 5, retry, A.counters);
+        hipLaunchKernelGGL(k_trace_shadow_retry, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow_retry)), dim3(RT_BLOCK), 0, st, S, again, ctrl + 4,
+                           (uint32_t)RT_BATCH1, A.counters);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_trace_shadow, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4,
+                       (uint32_t)RT_BATCH1, A.counters);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
