@@ -1039,11 +1039,12 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 }
                 if (mine) T.oi = o + 1;
             }
-            if (mode == TM_OBJ) {
+            {
                 // past the last object: the ray is done
+                const bool done = mode == TM_OBJ;
                 Hit h; h.t = T.t1; h.obj = T.hobj; h.prim = T.hprim;
-                src.store(T.item, T.hobj >= 0, h);
-                mode = TM_FETCH;
+                src.store_wave(done, T.item, T.hobj >= 0, h);
+                if (done) mode = TM_FETCH;
             }
         }
         RT_TICK(rays)
@@ -1267,6 +1268,7 @@ struct RaySrc {             // rt_trace_rays: caller's ray array
     __device__ uint32_t count() const { return n; }
     __device__ bool load(uint32_t i, V3 &e, V3 &d, double &a, double &b) const { e = ld3(rays[i].e); d = ld3(rays[i].d); a = t0; b = t1; return true; }
     __device__ void reload(uint32_t i, V3 &e, V3 &d) const { e = ld3(rays[i].e); d = ld3(rays[i].d); }
+    __device__ void store_wave(bool on, uint32_t i, bool hit, const Hit &h) const { if (on) store(i, hit, h); }
     __device__ void store(uint32_t i, bool hit, const Hit &h) const
     {
         prim_id[i] = hit ? global_prim(S, h) : RT_MISS;
@@ -1313,6 +1315,7 @@ struct PrimarySrc {         // rt_trace_primary: one ray through every pixel cen
         return true;
     }
     __device__ void reload(uint32_t i, V3 &e, V3 &d) const { double a, b; load(i, e, d, a, b); }
+    __device__ void store_wave(bool on, uint32_t i, bool hit, const Hit &h) const { if (on) store(i, hit, h); }
     __device__ void store(uint32_t i, bool hit, const Hit &hh) const
     {
         int x, y;
@@ -1482,8 +1485,10 @@ __device__ __forceinline__ uint64_t take_slot(SlotCursor &c, int pair, unsigned 
     return slot;
 }
 
-// First rays of work items [first, first+count): item = sample-major (all pixels of sample k,
-// then k+1) so that neighbouring lanes start neighbouring pixels with the same sample index.
+// First rays of work items [first, first+count): item = pixel-major (all samples of a pixel, then
+// the next pixel of the tile order), so that the lanes of a wave start out on one pixel or two:
+// their rays stay neighbours on the stacks, and what they add to the pixel is summed inside the
+// wave first (add_radiance_wave).
 __global__ __launch_bounds__(RT_BLOCK) void k_generate(DevScene S, WaveArgs A, RayDest D, uint64_t first, uint32_t count)
 {
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1497,10 +1502,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(DevScene S, WaveArgs A, R
         e = ld3(A.rays[item].e); d = ld3(A.rays[item].d);
         t1 = A.t1;
     } else {
-        const uint64_t npix = (uint64_t)A.width * (uint64_t)A.height;
-        k = (uint32_t)A.sample_begin + (uint32_t)(item / npix);
+        const uint32_t ns = (uint32_t)(A.sample_end - A.sample_begin);
+        k = (uint32_t)A.sample_begin + (uint32_t)(item % ns);
         int x, y;
-        work_pixel((uint32_t)(item % npix), A.width, A.height, x, y);
+        work_pixel((uint32_t)(item / ns), A.width, A.height, x, y);
         pix = (uint32_t)y * (uint32_t)A.width + (uint32_t)x;
         double jx, jy;                                          // Scene::run, scene.cpp:105-108
         jitter_pair(A.seed, pix, 0, k, (uint32_t)A.n, (uint32_t)A.m, jx, jy);
@@ -1521,6 +1526,34 @@ __device__ __forceinline__ void add_radiance(double *out, uint32_t pix, V3 v)
     if (v.x != 0.0) unsafeAtomicAdd(out + 3ull * pix, v.x);
     if (v.y != 0.0) unsafeAtomicAdd(out + 3ull * pix + 1, v.y);
     if (v.z != 0.0) unsafeAtomicAdd(out + 3ull * pix + 2, v.z);
+}
+
+// add_radiance for a whole wave (every lane calls it; `on` = this lane has something to add):
+// neighbouring lanes that add to the same pixel are summed first (a segmented scan over the runs
+// of equal pixels) and the last lane of a run adds the run's sum, so a pixel's 64 samples in one
+// wave cost one addition per channel instead of 64 to the same address.  With few such
+// neighbours the lanes add for themselves.
+__device__ __forceinline__ void add_radiance_wave(double *out, bool on, uint32_t pix, V3 v)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long act = ballot64(on);
+    if (act == 0ull) return;
+    const uint32_t key = on ? pix : 0xFFFFFFFFu;                  // lanes with nothing to add end a run
+    const uint32_t before = (uint32_t)__shfl_up((int)key, 1, 64);
+    const unsigned long long heads = ballot64(lane == 0u || before != key);
+    if (2u * (uint32_t)__popcll(heads & act) > (uint32_t)__popcll(act)) {
+        if (on) add_radiance(out, pix, v);
+        return;
+    }
+    if (!on) v = mk(0, 0, 0);
+    const uint32_t start = 63u - (uint32_t)__clzll((long long)(heads & (~0ull >> (63u - lane))));   // first lane of this lane's run
+#pragma unroll
+    for (uint32_t off = 1; off < 64u; off <<= 1) {
+        const V3 u = mk(__shfl_up(v.x, off, 64), __shfl_up(v.y, off, 64), __shfl_up(v.z, off, 64));
+        if (lane >= start + off) v = v + u;
+    }
+    const unsigned long long tails = (heads >> 1) | (1ull << 63);
+    if (on && ((tails >> lane) & 1ull)) add_radiance(out, pix, v);
 }
 
 // The shadow test for the chunk [base, base+count) of a shadow stack: group_->calHit(newray, ZERO,
@@ -1551,6 +1584,16 @@ struct ShadowSrc {
         if (hit) return;
         const uint64_t slot = base + i;
         add_radiance(out, q.pix[slot], mk(f(slot, SH_CX), f(slot, SH_CY), f(slot, SH_CZ)));
+    }
+    // store() for the lanes with `on`, called by the whole wave
+    __device__ void store_wave(bool on, uint32_t i, bool hit, const Hit &) const
+    {
+        const bool add = on && !hit;
+        const uint64_t slot = base + (add ? i : 0u);
+        uint32_t pix = 0;
+        V3 v = mk(0, 0, 0);
+        if (add) { pix = q.pix[slot]; v = mk(f(slot, SH_CX), f(slot, SH_CY), f(slot, SH_CZ)); }
+        add_radiance_wave(out, add, pix, v);
     }
 };
 RT_TRACE_ATTR
@@ -1586,6 +1629,7 @@ struct StackSrc {
         e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
         d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
     }
+    __device__ void store_wave(bool on, uint32_t i, bool hit, const Hit &h) const { if (on) store(i, hit, h); }
     __device__ void store(uint32_t i, bool hit, const Hit &h) const
     {
         const uint64_t slot = base + i;
@@ -1679,10 +1723,11 @@ __device__ __forceinline__ void sweep_rays(const DevScene &S, const Src &src, ui
                 if (hit) { t1 = t; hobj = o; hprim = 0; }
             }
         }
-        if (live && !defer) {
+        {
+            const bool done = live && !defer;
             Hit h; h.t = t1; h.obj = hobj; h.prim = hprim;
-            src.store(item, hobj >= 0, h);
-            c.rays++; c.leaf += nleaf; c.prim += nprim;
+            src.store_wave(done, item, hobj >= 0, h);
+            if (done) { c.rays++; c.leaf += nleaf; c.prim += nprim; }
         }
         const unsigned long long dm = ballot64(defer);
         if (dm != 0ull) {
@@ -1701,6 +1746,7 @@ struct RetrySrc {
     __device__ bool load(uint32_t i, V3 &e, V3 &d, double &t0, double &t1) const { return b.load(list[i], e, d, t0, t1); }
     __device__ void reload(uint32_t i, V3 &e, V3 &d) const { b.reload(list[i], e, d); }
     __device__ void store(uint32_t i, bool hit, const Hit &h) const { b.store(list[i], hit, h); }
+    __device__ void store_wave(bool on, uint32_t i, bool hit, const Hit &h) const { b.store_wave(on, on ? list[i] : 0u, hit, h); }
 };
 __global__ __launch_bounds__(RT_BLOCK) void k_sweep(DevScene S, StackSrc src, uint32_t *retry_count, uint32_t *retry_list)
 {
