@@ -40,6 +40,11 @@ VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (
                                # the path is built without contraction, so an operation is one flop)
 RAY_RECORD_BYTES = 88.0        # a pending bounce ray: 11 eight-byte fields
 SHADOW_RECORD_BYTES = 84.0     # a pending shadow ray: 10 eight-byte fields and the pixel index
+# a "launch" of the closest-hit stage is one call of the library's launcher: the engine over a chunk
+# of a ray stack, or -- for rays expected to stay outside the octrees -- the object-sweep kernel
+# followed by the engine over the rays that reached an octree after all
+TRACE_KERNELS = ("closest-hit stage: rt::k_trace / rt::k_trace_shadow (octree engine), "
+                 "rt::k_sweep / rt::k_sweep_shadow + rt::k_trace_retry / rt::k_trace_shadow_retry (rays outside the octrees)")
 SHADE_READ_BYTES = 40.0        # what shading reads of every ray: meta word, hit id, throughput
 
 
@@ -254,7 +259,7 @@ def main():
             "rays_per_path": rays_per_step / paths_per_step,
             "upload_s": upload_s,
             "workspace_gb": sc.workspace_bytes() / 1e9,
-            "roofline": {"kernel": "rt::k_trace (octree closest hit)", "bound": "valu-fp64",
+            "roofline": {"kernel": TRACE_KERNELS, "bound": "valu-fp64",
                          "achieved": achieved_ops / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": achieved_ops / VALU_FP64_PEAK, "traffic": traffic, "traffic_source": src,
                          "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_ops_per_launch": ops_per_launch,
@@ -271,7 +276,7 @@ def main():
         }
         if traffic and avg_ms > 0:
             gbs = traffic / (avg_ms * 1e-3) / 1e9
-            out["roofline_hbm"] = {"kernel": "rt::k_trace (octree closest hit)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            out["roofline_hbm"] = {"kernel": TRACE_KERNELS, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                                    "note": "measured traffic of the profiled run over this run's launch time: the scene is cache resident, HBM does not bind"}
         for key in ("roofline", "roofline_shade", "roofline_hbm"):

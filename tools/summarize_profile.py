@@ -68,8 +68,11 @@ def figures(*kernels):
 
 
 pmc = {"collected": f"{tag}, `bench.py --workload {workload} --steps 1 --warmup 0 --no-cpu-baseline`, FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes",
-       "trace": figures("rt::k_trace", "rt::k_trace_shadow"), "shade": figures("rt::k_shade"),
-       "k_trace": figures("rt::k_trace"), "k_trace_shadow": figures("rt::k_trace_shadow")}
+       "trace": figures("rt::k_trace", "rt::k_trace_shadow", "rt::k_sweep", "rt::k_sweep_shadow", "rt::k_trace_retry", "rt::k_trace_shadow_retry"),
+       "shade": figures("rt::k_shade"),
+       "k_trace": figures("rt::k_trace"), "k_trace_shadow": figures("rt::k_trace_shadow"),
+       "k_sweep": figures("rt::k_sweep"), "k_sweep_shadow": figures("rt::k_sweep_shadow"),
+       "k_trace_retry": figures("rt::k_trace_retry", "rt::k_trace_shadow_retry")}
 json.dump(pmc, open(os.path.join(OUT, f"pmc_{workload}.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(OUT, f"{tag}_{workload}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(pmc, indent=1))
