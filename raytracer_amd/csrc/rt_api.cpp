@@ -667,6 +667,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
                 s->dev.big_hi[b][k] = fresh ? hi : std::fmax(s->dev.big_hi[b][k], hi);
             }
         }
+    // RT_CLASS_GUESS=0 (a test switch): no boxes to guess with, every ray is class 0 and takes the
+    // sweep kernel's way, the rays that enter an octree being handed on to the engine
+    if (const char *g = std::getenv("RT_CLASS_GUESS")) if (g[0] == '0' && g[1] == 0) s->dev.nbig = 0;
     for (const FlatNode &f : nodes)
         for (int k = 0; k < 3; k++) {
             const double a = std::fabs(f.lo[k]), b = std::fabs(f.hi[k]);

@@ -767,3 +767,30 @@ def test_perlin_tables_drift_with_time():
     assert np.abs(first - i2).max() > 1e-3
     with pytest.raises(hip.RtError):
         sg.set_perlin(P[:64], G[:64])
+
+
+def test_rays_handed_on_from_the_sweep_kernel(monkeypatch):
+    """A ray's class (does it reach an octree's root box?) only picks the kernel: class 0 goes to the
+    object-sweep kernel, which hands a ray that reaches the box after all on to the engine.  The
+    guess is built to err towards class 1, so the hand-on never happens by itself; with the guess
+    switched off (RT_CLASS_GUESS=0: every ray is class 0) every ray that enters the mesh takes that
+    way, and paths, frames and work counters must still be the oracle's."""
+    desc, cam = scenes.bunny_cornell_scene(nu=40, nv=41, extras=True)
+    so = orc.OracleScene(desc)
+    monkeypatch.setenv("RT_CLASS_GUESS", "0")
+    sg = hip.HipScene(desc)
+    monkeypatch.delenv("RT_CLASS_GUESS")
+    c = hip.camera_init(**cam)
+    W, H = 96, 64
+    rays = _camera_rays(c, W, H)
+    prm = render_params(W, H, 1, seed=9)
+    c1, k1 = so.ray_color(rays, prm)
+    c2, k2 = sg.ray_color(rays, prm)
+    assert np.array_equal(k1, k2)
+    r = _rel(c1, c2).max(axis=1)
+    assert (r > PATH_RTOL).mean() <= 1e-4, r.max()
+    prm = render_params(W, H, 3, seed=9)
+    i1, q1 = so.render(orc.camera_init(**cam), prm)
+    i2, q2 = sg.render(c, prm)
+    assert np.array_equal(q1, q2)
+    assert np.sqrt((((i1 - i2) / 9) ** 2).mean()) <= RMSE_TOL
