@@ -27,13 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from raytracer_amd import hip, scenes  # noqa: E402
-from raytracer_amd.desc import render_params  # noqa: E402
-from raytracer_amd.parallel import dist_env, sample_slice  # noqa: E402
+from raytracer_amd.parallel import dist_env, sample_slice  # noqa: E402  (no GPU library behind this import)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (operations/s, a fused multiply-add = 1:
@@ -88,7 +82,7 @@ def cpu_baseline(desc, cam, W, H, n, m, seed, budget_s=20.0):
             "sample": f"{len(ys)} of {H} image rows (evenly spaced, full {n * m} spp each): {rays} rays in {dt:.1f} s"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -101,21 +95,74 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: samples per GPU fixed (default); strong: the frame fixed (bunny 256 spp, atrium 1024 spp), "
                          "its samples dealt to the ranks")
+    ap.add_argument("--reduce", choices=["torch", "native"], default="torch",
+                    help="the frame's one exchange step: torch.distributed.reduce (RCCL through torch; default) or the library's own "
+                         "rt_reduce_and_resolve (ncclReduce through the RCCL the process holds, unique id broadcast by torch)")
     ap.add_argument("--workspace-gb", type=float, default=0.0,
                     help="upper bound on the pending-ray stacks in GB (0 = the library's default: 16 Mi rays a round, at most a "
                          "quarter of the free device memory); RT_WAVEFRONT_RAYS in the environment sets the rays per round")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    a = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this process starts N rank processes (one per
+    GPU, the environment torch.distributed.run would give them) and never touches a GPU itself --
+    nothing that initialises the HIP runtime has been imported at this point.  Rank 0's JSON line is
+    passed through as this process's own; any rank failing fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RT_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:       # a rank left behind by a failed peer
+            p.kill()
+            codes.append(p.wait())
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank processes failed (rank, exit code): {bad}")
+
+
+def main():
+    a = parse_args()
     rank, local_rank, world = dist_env()
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("for --gpus > 1 launch with torch.distributed.run --nproc-per-node N")
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world == 1 and a.gpus > 1:
+        return spawn_ranks(a)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks")
+
+    global np, torch, dist, hip, scenes, render_params
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import hip, scenes
+    from raytracer_amd.desc import render_params
+
     # one rank per GPU; RT_BENCH_BACKEND=gloo lets several ranks share a card to rehearse the N > 1
     # path on a one-GPU box (RCCL refuses two ranks on one device)
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"--gpus {world} needs {world} devices, this machine shows {ndev} "
+                         "(RT_BENCH_BACKEND=gloo rehearses the N > 1 path with the ranks sharing a card)")
     if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
+        local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     hip.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -124,6 +171,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    native = world > 1 and a.reduce == "native"
+    comm = None
+    if native:
+        if backend != "nccl":
+            raise SystemExit("--reduce native needs one device per rank (RCCL)")
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(hip.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        comm = hip.Comm(unique_id=bytes(uid.cpu().numpy().tobytes()), nranks=world, rank=rank, device=local_rank)
 
     # rays per round: the library's default is 16 Mi; the benchmark has the card to itself and takes 32 Mi
     # (+3 % rays/s for twice the stack memory, reported as workspace_gb)
@@ -159,13 +216,20 @@ def main():
     bgr = torch.empty(H, W, 3, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        img.zero_()
-        sc.render_dev(c, prm, img.data_ptr(), cnt.data_ptr(), stream)
+    def exchange():
+        """The frame's one exchange step and the resolve on rank 0."""
+        if native:
+            comm.reduce_and_resolve(0, img.data_ptr(), W, H, n * m, bgr.data_ptr() if rank == 0 else 0, stream=stream)
+            return
         if world > 1:
             dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
             hip.resolve_bgr8_dev(img.data_ptr(), W, H, n * m, bgr.data_ptr(), stream)
+
+    def step():
+        img.zero_()
+        sc.render_dev(c, prm, img.data_ptr(), cnt.data_ptr(), stream)
+        exchange()
 
     def fence():
         if world > 1:
@@ -175,7 +239,7 @@ def main():
     if world > 1:
         # set up the collective's connections outside the timed region whatever --warmup is
         # (the first reduce of a communicator establishes them)
-        dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
+        exchange()
     for _ in range(a.warmup):
         step()
     fence()
@@ -194,9 +258,14 @@ def main():
     flow = sc.get_ray_flow()
     sc.set_profiling(False)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    total = cnt.clone()
+    small = dev if backend == "nccl" else torch.device("cpu")      # where the few bytes of bookkeeping are exchanged
+    tmax = torch.tensor([dt], dtype=torch.float64, device=small)
+    total = cnt.to(small)
+    rank_ms = [dt / max(a.steps, 1) * 1e3]
     if world > 1:
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)
+        rank_ms = [float(x.item()) / max(a.steps, 1) * 1e3 for x in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -254,6 +323,10 @@ def main():
                                    + f"{W}x{H} @ {per_gpu} spp per GPU ({n * m} spp total), max depth 40 / roulette from 12",
                        "width": W, "height": H, "spp_total": n * m, "spp_per_gpu": per_gpu, "triangles": ntris,
                        "parallelism": f"spp-partition x{world}, sum-reduce to rank 0"},
+            "rank_ms_per_step": rank_ms,
+            "rccl_nranks": (comm.size() if native else dist.get_world_size()) if world > 1 and backend == "nccl" else (1 if world == 1 else 0),
+            "reduce": "none (one rank)" if world == 1 else ("rt_reduce_and_resolve (ncclReduce)" if native else f"torch.distributed.reduce ({backend})"),
+            "launcher": "bench.py's own rank processes" if os.environ.get("RT_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "none"),
             "spp_per_s": n * m * steps / dt,
             "mpaths_per_s": paths_per_step * steps / dt / 1e6,
             "rays_per_path": rays_per_step / paths_per_step,
@@ -288,6 +361,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

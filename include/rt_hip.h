@@ -267,8 +267,13 @@ int rt_scene_get_ray_flow(rt_scene *scene, double out[6], int reset);
  * per scene handle, made by the first call that needs it, grown by later ones, freed by
  * rt_scene_destroy).  By default a call sizes its rounds to 16 Mi rays (RT_WAVEFRONT_RAYS in the
  * environment overrides) and never takes more than a quarter of the device memory that is free;
- * with a limit set, rounds shrink until the stacks fit `bytes` (0 = back to the default).  Smaller
- * rounds change speed only, never results.  rt_scene_workspace_bytes: what the handle holds now.
+ * with a limit set, rounds shrink until the stacks fit `bytes` (0 = back to the default) and an
+ * allocation made earlier that is larger than the limit is freed and made anew by the next call.
+ * The smallest round is 65 536 rays: a limit below what that needs for the scene's materials and
+ * lights makes the next rt_render / rt_ray_color fail (-1) instead of exceeding it.  The default
+ * policy looks at the free memory of the moment, so several handles on one device that render at
+ * the same time can each take a quarter of it: give them limits.  Smaller rounds change speed
+ * only, never results.  rt_scene_workspace_bytes: what the handle holds now.
  * No counterpart in the reference. */
 int rt_scene_set_workspace_limit(rt_scene *scene, uint64_t bytes);
 int64_t rt_scene_workspace_bytes(const rt_scene *scene);

@@ -444,7 +444,10 @@ private:
         if (ndev > 1) {
             std::vector<int> devices(ndev);
             for (int i = 0; i < ndev; i++) devices[i] = i;
-            if (rt_multi_create(&d, devices.data(), ndev, RT_REDUCE_RCCL, &multi_)) return -1;
+            // the members' sums meet through RCCL; where that cannot be set up (no loadable RCCL, a
+            // communicator that will not form) they meet in host memory instead -- same frame, slower exchange
+            if (rt_multi_create(&d, devices.data(), ndev, RT_REDUCE_RCCL, &multi_) &&
+                rt_multi_create(&d, devices.data(), ndev, RT_REDUCE_HOST, &multi_)) return -1;
         } else if (rt_scene_create(&d, &handle_)) return -1;
         dirty_ = false;
         return 0;

@@ -813,7 +813,9 @@ static void carve_workspace(void *base, uint64_t target, uint64_t P, uint64_t L,
 // One allocation of at least `bytes`, or none: a failed allocation leaves the scene without a workspace.
 static int ensure_workspace(rt_scene *s, uint64_t bytes, hipStream_t st)
 {
-    if (s->ws_mem && s->ws_bytes >= bytes) return 0;
+    // an allocation made before a (smaller) limit was set is given back, not kept
+    const bool over_limit = s->ws_limit && s->ws_bytes > s->ws_limit;
+    if (s->ws_mem && s->ws_bytes >= bytes && !over_limit) return 0;
     HIP_TRY(hipStreamSynchronize(st));
     if (s->ws_mem) { (void)hipFree(s->ws_mem); s->ws_mem = nullptr; s->ws_bytes = 0; }
     void *mem = nullptr;
@@ -921,6 +923,10 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
         }
     }
     for (int k = 0; k < 2; k++) if (int rc = drain(k)) return rc;
+    // the last shadow tests still read the shadow stacks: the call returns when they are done, so that
+    // the caller may hand the workspace (or the static one, which every scene of the device shares)
+    // to the next call on any stream
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -948,6 +954,9 @@ static int run_wavefront(rt_scene *s, WaveArgs &A, uint64_t total_items, hipStre
     }
     while (target > (1u << 16) && (workspace_bytes(target, P, L) > limit || target * (P + 3) >= 0xFFFFFFF0ull || target * (L + 1) >= 0xFFFFFFF0ull)) target >>= 1;
     if (target * (P + 3) >= 0xFFFFFFF0ull || target * (L + 1) >= 0xFFFFFFF0ull) return fail("render: ray stack too large");
+    if (s->ws_limit && workspace_bytes(target, P, L) > s->ws_limit)
+        return fail("render: the workspace limit of " + std::to_string(s->ws_limit) + " bytes is below the smallest round (65536 rays need " +
+                    std::to_string(workspace_bytes(target, P, L)) + " bytes for this scene's materials and lights)");
     // on a device with less memory than that fall back to smaller rounds rather than fail
     for (;;) {
         const int rc = ensure_workspace(s, workspace_bytes(target, P, L), st);

@@ -633,7 +633,10 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             }
             // LDS operations of one wave are carried out in the order they are issued, so each stage
             // below sees the stage before it; the wave barriers only keep the compiler from mixing them
-            const unsigned long long key = ordered_key(tt);
+            // -0.0 and +0.0 are one distance to `t <= tempt` (octree.cpp:31), so they share a key; the
+            // winner's own sign of zero travels in the free top bit of the id word
+            const unsigned long long key = ordered_key(tt + 0.0);
+            if (tt == 0.0 && __builtin_signbit(tt)) id |= 0x80000000u;
 #if RT_STEP_STATS == 8
             if (__builtin_amdgcn_readfirstlane((int)(key != 0ull)) >= 0 && lane == 0) c.prim += (uint32_t)((clock64() - tp0) >> 4);
 #endif
@@ -647,7 +650,10 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                 const unsigned long long k = L.okey[lane];
                 if (k != ~0ull) {
                     const double t = ordered_value(k);
-                    if (t <= T.tempt) { T.tempt = t; T.bprim = (uint32_t)L.owin[lane]; }      // octree.cpp:30-33
+                    if (t <= T.tempt) {                                                       // octree.cpp:30-33
+                        const uint32_t w = (uint32_t)L.owin[lane];
+                        T.tempt = (w & 0x80000000u) ? -0.0 : t; T.bprim = w & 0x7FFFFFFFu;
+                    }
                 }
             }
             tested += n;

@@ -32,6 +32,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
@@ -56,6 +57,7 @@ const Rccl *rccl(std::string &why)
         R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
         R.CommInitAll = (decltype(R.CommInitAll))sym("ncclCommInitAll");
         R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+        R.CommAbort = (decltype(R.CommAbort))sym("ncclCommAbort");
         R.Reduce = (decltype(R.Reduce))sym("ncclReduce");
         R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
     });
@@ -76,7 +78,54 @@ struct rt_comm {
     int nranks = 0, rank0 = 0;
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
+    std::mutex mu;
+    bool aborted = false;       // a member could not enter a collective: the handles were aborted and are gone
 };
+
+namespace {
+
+// A local member cannot enter the collective its peers are entering (or already wait in): abort
+// every local handle, which makes the collective's kernels on the peers' streams give up instead
+// of waiting for ever.  The communicator is unusable afterwards.
+void abort_comm(rt_comm *c)
+{
+    std::string why;
+    const Rccl *R = rccl(why);
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->aborted) return;
+    c->aborted = true;
+    for (size_t i = 0; i < c->comms.size(); i++)
+        if (R && R->CommAbort && c->comms[i]) { (void)R->CommAbort(c->comms[i]); c->comms[i] = nullptr; }
+}
+
+// rt_reduce_and_resolve; `entered` says whether this member's ncclReduce was issued
+int reduce_and_resolve(rt_comm *c, int member, double *radiance_sum, int w, int h, int spp, int tone, uint8_t *bgr, void *stream, bool *entered)
+{
+    *entered = false;
+    if (!c || member < 0 || member >= (int)c->comms.size()) return rt::set_error("rt_reduce_and_resolve: bad communicator member", -1);
+    if (!radiance_sum || w <= 0 || h <= 0 || spp <= 0) return rt::set_error("rt_reduce_and_resolve: bad argument", -1);
+    std::string why;
+    const Rccl *R = rccl(why);
+    if (!R) return rt::set_error(why, -3);
+    ncclComm_t handle;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (c->aborted) return rt::set_error("rt_reduce_and_resolve: the communicator was aborted after a member failed", -3);
+        handle = c->comms[member];
+    }
+    hipError_t he = hipSetDevice(c->devices[member]);
+    if (he != hipSuccess) return rt::set_error(std::string("hipSetDevice: ") + hipGetErrorString(he), -2);
+    const bool root = c->rank0 + member == 0;
+    // a direct reduce onto the root: one 8 w h 3 byte buffer per frame (25 MB at 1024 x 1024); on a
+    // point-to-point fabric the root takes its peers' buffers over separate links
+    *entered = true;
+    const ncclResult_t e = R->Reduce(radiance_sum, radiance_sum, (size_t)w * (size_t)h * 3u, ncclFloat64, ncclSum, 0, handle, (hipStream_t)stream);
+    if (e != ncclSuccess) return fail_nccl(R, "ncclReduce", e);
+    if (root && bgr) return rt_resolve_tone_bgr8(radiance_sum, w, h, spp, tone, bgr, stream);
+    return 0;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -147,20 +196,8 @@ int rt_comm_size(const rt_comm *c) { return c ? c->nranks : rt::set_error("rt_co
 
 int rt_reduce_and_resolve(rt_comm *c, int member, double *radiance_sum, int w, int h, int spp, int tone, uint8_t *bgr, void *stream)
 {
-    if (!c || member < 0 || member >= (int)c->comms.size()) return rt::set_error("rt_reduce_and_resolve: bad communicator member", -1);
-    if (!radiance_sum || w <= 0 || h <= 0 || spp <= 0) return rt::set_error("rt_reduce_and_resolve: bad argument", -1);
-    std::string why;
-    const Rccl *R = rccl(why);
-    if (!R) return rt::set_error(why, -3);
-    hipError_t he = hipSetDevice(c->devices[member]);
-    if (he != hipSuccess) return rt::set_error(std::string("hipSetDevice: ") + hipGetErrorString(he), -2);
-    const bool root = c->rank0 + member == 0;
-    // a direct reduce onto the root: one 8 w h 3 byte buffer per frame (25 MB at 1024 x 1024); on a
-    // point-to-point fabric the root takes its peers' buffers over separate links
-    const ncclResult_t e = R->Reduce(radiance_sum, radiance_sum, (size_t)w * (size_t)h * 3u, ncclFloat64, ncclSum, 0, c->comms[member], (hipStream_t)stream);
-    if (e != ncclSuccess) return fail_nccl(R, "ncclReduce", e);
-    if (root && bgr) return rt_resolve_tone_bgr8(radiance_sum, w, h, spp, tone, bgr, stream);
-    return 0;
+    bool entered;
+    return reduce_and_resolve(c, member, radiance_sum, w, h, spp, tone, bgr, stream, &entered);
 }
 
 } // extern "C"
@@ -284,10 +321,14 @@ int rt_multi_render(rt_multi *M, const rt_camera *cam, const rt_render_params *p
         int rc = rc0 ? rc0 : rt_render(q.scene, cam, &p, q.sum, q.counters, nullptr);
         if (rc == 0) rc = rt_scene_check(q.scene, nullptr);
         // a member that failed still enters the reduce (its partial buffer is discarded with the frame):
-        // leaving the others waiting in the collective would hang them
+        // leaving the others waiting in the collective would hang them; one that cannot even enter it
+        // aborts the communicator, which releases them with an error
         if (M->comm) {
-            const int rr = rt_reduce_and_resolve(M->comm, i, q.sum, params->width, params->height, spp, tone, i == 0 ? q.bgr : nullptr, nullptr);
-            if (rc == 0) rc = rr;
+            bool entered = false;
+            const std::string keep = rc ? rt_last_error() : "";
+            const int rr = reduce_and_resolve(M->comm, i, q.sum, params->width, params->height, spp, tone, i == 0 ? q.bgr : nullptr, nullptr, &entered);
+            if (!entered) abort_comm(M->comm);
+            if (rc == 0) rc = rr; else rt::set_error(keep, rc);
         }
         e = hipDeviceSynchronize();
         if (rc == 0 && e != hipSuccess) rc = rt::set_error(std::string("hipDeviceSynchronize: ") + hipGetErrorString(e), -2);

@@ -79,3 +79,34 @@ def test_reduce_and_resolve_one_process_per_gpu_form():
     with pytest.raises(hip.RtError):
         comm.reduce_and_resolve(3, d.data_ptr(), W, H, spp, out.data_ptr())
     comm.close()
+
+
+def test_bench_starts_its_own_rank_processes_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the script starts one process per rank itself
+    and rank 0's line comes out as its own.  Rehearsed here with both ranks on the one card (gloo
+    carries the reduce; on a multi-GPU node the same path runs over RCCL, one device per rank)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--size", "96", "--spp-root", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "Mrays/s" and d["value"] > 0
+    assert d["config"]["spp_total"] == 32 and d["config"]["spp_per_gpu"] == 16
+    assert len(d["rank_ms_per_step"]) == 2 and max(d["rank_ms_per_step"]) == pytest.approx(d["ms_per_step"])
+    assert d["launcher"] == "bench.py's own rank processes" and d["rccl_nranks"] == 0 and "gloo" in d["reduce"]
+    assert d["cpu_baseline"] is None and 0 < d["roofline"]["frac"] <= 1
+    # more ranks than devices over RCCL is refused with a clear message, before any rendering
+    env2 = dict(env); env2.pop("RT_BENCH_BACKEND")
+    import torch
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--steps", "1", "--warmup", "0",
+                          "--size", "96", "--spp-root", "4", "--no-cpu-baseline"], env=env2, capture_output=True, text=True, timeout=280)
+    assert bad.returncode != 0 and "devices" in bad.stderr

@@ -73,3 +73,53 @@ def test_noalloc_entry_matches_allocating_entry_twice_in_a_row():
     assert L.rt_ray_color_noalloc(sc2._h, buf.data_ptr(), (1 << 20) + 1, 0.0, 1e10, 0, C.byref(prm), buf.data_ptr(), None, None) != 0
     assert b"1048576" in L.rt_last_error()
     assert L.rt_ray_color_noalloc(sc2._h, buf.data_ptr(), 0, 0.0, 1e10, 0, C.byref(prm), buf.data_ptr(), None, None) == 0
+
+
+def test_noalloc_allocates_nothing_and_two_calls_on_two_streams_in_a_row():
+    """On a scene handle that has never rendered, the entry point leaves the handle without a
+    workspace and the device's free memory where it was; and a second call on another stream right
+    behind the first (no synchronisation by the caller in between: each call returns with its work
+    complete) does not disturb the first one's result."""
+    import torch
+    L = hip.lib()
+    hip.set_device(0)
+    dev = torch.device("cuda:0")
+    desc, cam = scenes.bunny_cornell_scene(nu=60, nv=61, extras=True)
+    prm = render_params(1, 1, 1, seed=7, max_jump=24)
+    ra, rb = _camera_rays(cam, 200, 120, 11), _camera_rays(cam, 90, 70, 12)
+    # kernels loaded and reference results made with another handle first
+    other = hip.HipScene(desc)
+    ref_a, k_a = _run(L.rt_ray_color, other, ra, prm, 0.0, 1e10, 0)
+    ref_b, k_b = _run(L.rt_ray_color, other, rb, prm, 0.0, 1e10, 0)
+    _run(L.rt_ray_color_noalloc, other, rb, prm, 0.0, 1e10, 0)
+    # the two streams have run the entry point's kernels once (a stream's first use takes queue memory of its own)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    n = len(rb)
+    w_r = torch.from_numpy(rb.view(np.float64).reshape(n, 6).copy()).to(dev)
+    w_o = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for st in (s1, s2):
+        assert L.rt_ray_color_noalloc(other._h, w_r.data_ptr(), n, 0.0, 1e10, 0, C.byref(prm), w_o.data_ptr(), None, st.cuda_stream) == 0
+    torch.cuda.synchronize()
+    other.close()
+
+    sc = hip.HipScene(desc)
+    bufs = []
+    for rays in (ra, rb):
+        n = len(rays)
+        bufs.append((torch.from_numpy(rays.view(np.float64).reshape(n, 6).copy()).to(dev),
+                     torch.full((n, 3), 7.0, dtype=torch.float64, device=dev), torch.zeros(4, dtype=torch.int64, device=dev)))
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    for (r, o, c), st in zip(bufs, (s1, s2)):
+        rc = L.rt_ray_color_noalloc(sc._h, r.data_ptr(), r.shape[0], 0.0, 1e10, 0, C.byref(prm), o.data_ptr(), c.data_ptr(), st.cuda_stream)
+        assert rc == 0, L.rt_last_error()
+    torch.cuda.synchronize()
+    free_after = torch.cuda.mem_get_info(dev)[0]
+    assert sc.workspace_bytes() == 0                       # the handle never got a workspace of its own
+    assert abs(free_before - free_after) < (8 << 20)       # rt_ray_color would have taken >= 100 MB for its stacks
+    for (r, o, c), ref, kref in zip(bufs, (ref_a, ref_b), (k_a, k_b)):
+        got = o.cpu().numpy()
+        assert np.array_equal(c.cpu().numpy(), kref)
+        err = np.abs(got - ref) / np.maximum(1e-30, np.maximum(np.abs(got), np.abs(ref)))
+        assert err.max() <= 1e-12, err.max()
