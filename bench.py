@@ -288,7 +288,9 @@ def main():
         achieved_ops = ops_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         pmc = {}
         pfile = os.path.join(ROOT, "profiles", "pmc_" + a.workload + ".json")
-        if os.path.exists(pfile):
+        # the counter passes were made on the default frame of the workload (per GPU: weak scaling keeps it);
+        # any other frame has no measured traffic to report
+        if os.path.exists(pfile) and a.size == 1024 and a.spp_root == 16 and (a.scaling == "weak" or world == 1):
             try:
                 pmc = json.load(open(pfile))
             except Exception:

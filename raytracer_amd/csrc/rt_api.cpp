@@ -15,6 +15,7 @@
 #include "rt_internal.h"
 #include "rt_kernels.h"
 #include "rt_octree.h"
+#include "rt_pretest.h"
 
 using namespace rt;
 
@@ -243,213 +244,6 @@ int rt_scene_destroy(rt_scene *s)
     return 0;
 }
 
-// ---------------------------------------------------------------- pre-test spheres
-// Every record of a node's run gets a bounding sphere for the kernels' single-precision pre-test,
-// expressed in the node's own grid (rt_device.h: the node's box starts at RT_SPH_ORG and its longest
-// edge is RT_SPH_EDGE units), so that centre and radius are small integers and a 16-byte load
-// brings several spheres.  The grid's scale (units per length) is a float stored in the node record,
-// which the kernels use to bring the ray into the same grid.
-struct SphereD { double c[3], r; bool ok; };
-
-// the box's centre and half diagonal
-static SphereD voxel_sphere(const LeafTri &t)
-{
-    SphereD s; double r2 = 0;
-    for (int k = 0; k < 3; k++) { s.c[k] = (t.v0[k] + t.e1[k]) / 2; const double h = (t.e1[k] - t.v0[k]) / 2; r2 += h * h; }
-    s.r = std::sqrt(r2);
-    s.ok = std::isfinite(s.c[0]) && std::isfinite(s.c[1]) && std::isfinite(s.c[2]) && std::isfinite(s.r);
-    return s;
-}
-
-// The smallest sphere around the triangle (v0, v0+e1, v0+e2): centred on the middle of the longest
-// edge when the opposite angle is right or obtuse, else on the circumcentre; if the circumcentre
-// comes out badly (a nearly degenerate triangle) or gives a larger sphere than the centroid, the
-// centroid is used.  Whatever the centre, the radius is the largest vertex distance from it, so
-// the sphere contains the triangle by construction.
-static SphereD triangle_sphere(const LeafTri &t)
-{
-    double v[3][3], c[3];
-    for (int k = 0; k < 3; k++) { v[0][k] = t.v0[k]; v[1][k] = t.v0[k] + t.e1[k]; v[2][k] = t.v0[k] + t.e2[k]; }
-    double len2[3];
-    for (int i = 0; i < 3; i++) {
-        const double *p = v[(i + 1) % 3], *q = v[(i + 2) % 3];
-        len2[i] = (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]);
-    }
-    int lg = len2[0] >= len2[1] ? (len2[0] >= len2[2] ? 0 : 2) : (len2[1] >= len2[2] ? 1 : 2);
-    if (len2[lg] >= len2[(lg + 1) % 3] + len2[(lg + 2) % 3]) {
-        for (int k = 0; k < 3; k++) c[k] = (v[(lg + 1) % 3][k] + v[(lg + 2) % 3][k]) / 2;
-    } else {
-        // circumcentre = v0 + (|b|^2 (a x b) x a + |a|^2 b x (a x b)) / (2 |a x b|^2), a = e1, b = e2
-        const double *a = t.e1, *bb = t.e2;
-        const double n[3] = {a[1] * bb[2] - a[2] * bb[1], a[2] * bb[0] - a[0] * bb[2], a[0] * bb[1] - a[1] * bb[0]};
-        const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-        const double a2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], b2 = bb[0] * bb[0] + bb[1] * bb[1] + bb[2] * bb[2];
-        const double nxa[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0]};
-        const double bxn[3] = {bb[1] * n[2] - bb[2] * n[1], bb[2] * n[0] - bb[0] * n[2], bb[0] * n[1] - bb[1] * n[0]};
-        bool ok = n2 > 0 && std::isfinite(n2);
-        for (int k = 0; k < 3 && ok; k++) {
-            c[k] = t.v0[k] + (b2 * nxa[k] + a2 * bxn[k]) / (2 * n2);
-            ok = std::isfinite(c[k]);
-        }
-        if (!ok) for (int k = 0; k < 3; k++) c[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
-    }
-    double r2 = 0;
-    for (int i = 0; i < 3; i++) {
-        double d2 = 0;
-        for (int k = 0; k < 3; k++) d2 += (v[i][k] - c[k]) * (v[i][k] - c[k]);
-        if (!(d2 <= r2)) r2 = d2;
-    }
-    {
-        double g[3], rg2 = 0;
-        for (int k = 0; k < 3; k++) g[k] = (v[0][k] + v[1][k] + v[2][k]) / 3.0;
-        for (int i = 0; i < 3; i++) {
-            double d2 = 0;
-            for (int k = 0; k < 3; k++) d2 += (v[i][k] - g[k]) * (v[i][k] - g[k]);
-            if (!(d2 <= rg2)) rg2 = d2;
-        }
-        if (rg2 < r2) { r2 = rg2; for (int k = 0; k < 3; k++) c[k] = g[k]; }
-    }
-    SphereD s;
-    for (int k = 0; k < 3; k++) s.c[k] = c[k];
-    s.r = std::sqrt(r2);
-    s.ok = std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(s.r);
-    return s;
-}
-
-// The sphere for a triangle record of node n: around the part of the triangle that lies inside the
-// node's box.  A primitive test only accepts a hit inside the node's window, the stretch of the ray
-// inside the box (octree.cpp:19-38 with the window of algorithms.h:223-236), so the rest of the
-// triangle cannot be hit from this run, and a triangle much larger than the node (a wall crossing
-// many leaves) gets a sphere of the node's size instead of its own.  The box is grown by 1/64 of its
-// longest edge on every side first: the window's ends are rounded distances, and the hit point of
-// a distance inside the window may lie outside the box by that rounding (of the order of 1e-16 of
-// the distance the ray has travelled; 1/64 of the node's edge is beyond that for any ray that
-// double precision can place in the node at all).  Clipping is Sutherland-Hodgman against the six
-// planes; the sphere is centred on the middle of the clipped polygon's bounds and reaches its
-// farthest corner.  The triangle's own sphere is kept when it is the smaller one; a triangle that
-// misses the grown box gets an empty sphere at the box's corner.
-static SphereD clipped_triangle_sphere(const LeafTri &t, const FlatNode &n)
-{
-    const SphereD whole = triangle_sphere(t);
-    double ext = 0;
-    for (int k = 0; k < 3; k++) { const double e = n.hi[k] - n.lo[k]; if (!(e <= ext)) ext = e; }
-    if (!whole.ok || !std::isfinite(ext) || !(ext > 0)) return whole;
-    const double grow = ext / 64;
-    double poly[2][16][3];
-    int cnt = 3, cur = 0;
-    for (int k = 0; k < 3; k++) { poly[0][0][k] = t.v0[k]; poly[0][1][k] = t.v0[k] + t.e1[k]; poly[0][2][k] = t.v0[k] + t.e2[k]; }
-    for (int k = 0; k < 3 && cnt; k++) {
-        for (int side = 0; side < 2 && cnt; side++) {
-            const double plane = side ? n.hi[k] + grow : n.lo[k] - grow;
-            const double sgn = side ? -1.0 : 1.0;                 // inside: sgn * (x - plane) >= 0
-            double (*in)[3] = poly[cur], (*out)[3] = poly[cur ^ 1];
-            int m = 0;
-            for (int i = 0; i < cnt; i++) {
-                const double *a = in[i], *b = in[(i + 1) % cnt];
-                const double da = sgn * (a[k] - plane), db = sgn * (b[k] - plane);
-                if (!std::isfinite(da) || !std::isfinite(db)) return whole;
-                if (da >= 0) { for (int c = 0; c < 3; c++) out[m][c] = a[c]; m++; }
-                if ((da >= 0) != (db >= 0)) {
-                    const double u = da / (da - db);
-                    for (int c = 0; c < 3; c++) out[m][c] = a[c] + (b[c] - a[c]) * u;
-                    out[m][k] = plane;
-                    m++;
-                }
-                if (m > 14) return whole;                         // cannot happen: a triangle cut by six planes has at most nine corners
-            }
-            cnt = m; cur ^= 1;
-        }
-    }
-    SphereD s;
-    s.ok = true;
-    if (cnt == 0) {
-        for (int k = 0; k < 3; k++) s.c[k] = n.lo[k];
-        s.r = 0;
-        return s;
-    }
-    double lo[3], hi[3];
-    for (int k = 0; k < 3; k++) { lo[k] = hi[k] = poly[cur][0][k]; }
-    for (int i = 1; i < cnt; i++)
-        for (int k = 0; k < 3; k++) { if (poly[cur][i][k] < lo[k]) lo[k] = poly[cur][i][k]; if (poly[cur][i][k] > hi[k]) hi[k] = poly[cur][i][k]; }
-    double r2 = 0;
-    for (int k = 0; k < 3; k++) s.c[k] = (lo[k] + hi[k]) / 2;
-    for (int i = 0; i < cnt; i++) {
-        double d2 = 0;
-        for (int k = 0; k < 3; k++) d2 += (poly[cur][i][k] - s.c[k]) * (poly[cur][i][k] - s.c[k]);
-        if (!(d2 <= r2)) r2 = d2;
-    }
-    s.r = std::sqrt(r2) * (1.0 + 1e-9);                           // the cut points are rounded
-    s.ok = std::isfinite(s.c[0]) && std::isfinite(s.c[1]) && std::isfinite(s.c[2]) && std::isfinite(s.r);
-    if (!s.ok || whole.r <= s.r) return whole;
-    return s;
-}
-
-// A sphere that holds the whole node in the node's grid (the box reaches at most RT_SPH_EDGE units
-// along every axis from RT_SPH_ORG, so its corners are within 0.9 RT_SPH_EDGE of RT_SPH_MID and the
-// largest radius is two edges): the pre-test passes
-// every ray that crosses the box.  The primitive tests only accept hits inside the node's window,
-// i.e. inside the box, so this is a valid stand-in for any record whose own sphere cannot be
-// expressed.
-static void store_sphere(uint32_t *dst, uint32_t x, uint32_t y, uint32_t z, uint32_t r)
-{
-#if RT_SPH_BITS == 8
-    dst[0] = x | (y << 8) | (z << 16) | (r << 24);
-#else
-    dst[0] = x | (y << 16);
-    dst[1] = z | (r << 16);
-#endif
-}
-static void store_whole_node_sphere(uint32_t *dst) { store_sphere(dst, RT_SPH_MID, RT_SPH_MID, RT_SPH_MID, RT_SPH_MAX); }
-
-// Units per length of a node's grid, as the float the kernels multiply with; 0 (pre-test off for
-// the node: every record gets the whole-node sphere) when the box is degenerate or so large or
-// small that single precision cannot hold the scale.  The lowest mantissa bit is cleared because
-// the node record keeps a flag there.
-static float node_grid_scale(const FlatNode &n)
-{
-    double ext = 0;
-    for (int k = 0; k < 3; k++) {
-        const double e = n.hi[k] - n.lo[k];
-        if (!std::isfinite(e) || !std::isfinite(n.lo[k])) return 0.0f;
-        if (e > ext) ext = e;
-    }
-    if (!(ext > 0)) return 0.0f;
-    const double sc = (double)RT_SPH_EDGE / ext;
-    if (!(sc > 1e-30 && sc < 1e30)) return 0.0f;
-    float f = (float)sc;
-    uint32_t bits;
-    std::memcpy(&bits, &f, 4);
-    bits &= ~1u;                                      // rounds the scale down by at most one ulp: the box still fits
-    if ((double)f > sc) bits -= 2u;                   // never above RT_SPH_EDGE / ext
-    std::memcpy(&f, &bits, 4);
-    return f;
-}
-
-// The record's sphere in the node's grid, rounded outwards: the centre goes to the nearest grid
-// point and the radius grows by the distance it moved, by 1e-5 of itself (the primitive tests
-// accept rays that graze the primitive within rounding) and by 1/127 000 of the node's edge (the
-// kernels' own rounding when they bring the ray into the grid), then up to the next integer.
-static void pack_sphere(uint32_t *dst, const SphereD &s, const FlatNode &n, float scale)
-{
-    store_whole_node_sphere(dst);
-    if (!s.ok || !(scale > 0.0f)) return;
-    const double sc = (double)scale;
-    double disp2 = 0;
-    uint32_t q[3];
-    for (int k = 0; k < 3; k++) {
-        const double g = (s.c[k] - n.lo[k]) * sc + (double)RT_SPH_ORG;
-        if (!std::isfinite(g)) return;
-        double r = std::floor(g + 0.5);
-        if (r < 0) r = 0;
-        if (r > (double)RT_SPH_MAX) r = (double)RT_SPH_MAX;
-        q[k] = (uint32_t)r;
-        disp2 += (g - r) * (g - r);
-    }
-    const double rg = s.r * sc * (1.0 + 1e-5) + std::sqrt(disp2) * (1.0 + 1e-9) + 1e-3 * (RT_SPH_EDGE / 127u);
-    if (!(rg <= (double)RT_SPH_MAX)) return;
-    store_sphere(dst, q[0], q[1], q[2], (uint32_t)std::ceil(rg));
-}
-
 int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
 {
     if (!d || !out) return fail("rt_scene_create: null argument");
@@ -603,25 +397,41 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         const double inv = 1 / std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
         for (int k = 0; k < 3; k++) tri_normals[3 * i + k] = n[k] * inv;
     }
-    // spare spheres at the end: the kernels fetch a chunk of RT_SPH_SPARE spheres from any record on without clamping
-    std::vector<uint32_t> leaf_sph((leaf_tris.size() + RT_SPH_SPARE) * RT_SPH_WORDS);
-    for (size_t i = 0; i < leaf_tris.size() + RT_SPH_SPARE; i++) store_whole_node_sphere(&leaf_sph[i * RT_SPH_WORDS]);
-    for (FlatNode &n : nodes) {
+    // One box per record (same index) and one per segment of RT_SEG_RECS records of a node's run: the
+    // union of its records' boxes, found by the kernels at (obj_begin / RT_SEG_RECS) + node index + segment
+    // number -- runs lie in node order, so these places are distinct and in order (a run of c records has at
+    // most c / RT_SEG_RECS + 1 segments).  Spare boxes behind the last record: the kernels read the boxes of
+    // a whole segment from any record on.
+    std::vector<uint32_t> leaf_box((leaf_tris.size() + RT_SPH_SPARE) * 2);
+    std::vector<uint32_t> seg_box((leaf_tris.size() / RT_SEG_RECS + nodes.size() + 2) * 2);
+    for (size_t i = 0; i < leaf_box.size() / 2; i++) store_whole_node_box(&leaf_box[2 * i]);
+    for (size_t i = 0; i < seg_box.size() / 2; i++) store_whole_node_box(&seg_box[2 * i]);
+    for (size_t ni = 0; ni < nodes.size(); ni++) {
+        FlatNode &n = nodes[ni];
         const float scale = node_grid_scale(n);
         uint32_t bits;
         std::memcpy(&bits, &scale, 4);
         n.pad = bits | (n.pad & 1u);                  // grid scale, voxel flag in the lowest bit
-        for (uint32_t i = n.obj_begin; i < n.obj_begin + n.obj_count; i++)
-            pack_sphere(&leaf_sph[(size_t)i * RT_SPH_WORDS], (leaf_tris[i].id & LEAF_VOXEL) ? voxel_sphere(leaf_tris[i]) : clipped_triangle_sphere(leaf_tris[i], n), n, scale);
+        const size_t seg0 = (size_t)(n.obj_begin / RT_SEG_RECS) + ni;
+        for (uint32_t j = 0; j < n.obj_count; j += RT_SEG_RECS) {
+            int ulo[3] = {256, 256, 256}, uhi[3] = {-1, -1, -1};
+            for (uint32_t i = n.obj_begin + j; i < n.obj_begin + n.obj_count && i < n.obj_begin + j + RT_SEG_RECS; i++) {
+                int lo[3], hi[3];
+                const BoxD b = (leaf_tris[i].id & LEAF_VOXEL) ? clipped_voxel_box(leaf_tris[i], n) : clipped_triangle_box(leaf_tris[i], n);
+                pack_box(&leaf_box[(size_t)i * 2], b, n, scale, lo, hi);
+                for (int k = 0; k < 3; k++) { if (lo[k] < ulo[k]) ulo[k] = lo[k]; if (hi[k] > uhi[k]) uhi[k] = hi[k]; }
+            }
+            store_grid_box(&seg_box[(seg0 + j / RT_SEG_RECS) * 2], ulo, uhi);
+        }
     }
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
-    void *p_pp = nullptr, *p_pg = nullptr;
+    void *p_pp = nullptr, *p_pg = nullptr, *p_seg = nullptr;
     auto up = [&](auto &vec, void **dst) {
         if (e != hipSuccess) return;
         e = upload(vec, dst);
         if (*dst) s->allocs.push_back(*dst);
     };
-    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tri_normals, &p_tris); up(leaf_sph, &p_sph);
+    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tri_normals, &p_tris); up(leaf_box, &p_sph); up(seg_box, &p_seg);
     up(perlin_p, &p_pp); up(perlin_g, &p_pg);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
@@ -631,7 +441,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.lights = (const rt_light *)p_light;
     s->dev.nodes = (const FlatNode *)p_nodes;
     s->dev.leaf_tris = (const LeafTri *)p_idx;
-    s->dev.leaf_sph = (const uint32_t *)p_sph;
+    s->dev.leaf_box = (const uint32_t *)p_sph;
+    s->dev.seg_box = (const uint32_t *)p_seg;
     s->dev.tri_normals = (const double *)p_tris;
     s->dev.perlin_p = (const int32_t *)p_pp;
     s->dev.perlin_g = (const double *)p_pg;

@@ -7,22 +7,15 @@
 
 namespace rt {
 
-// Bounding spheres of the records of a node's run, for the kernels' single-precision pre-test.
-// They live in the node's own grid, RT_SPH_BITS bits a coordinate: the node's box starts at
-// RT_SPH_ORG on every axis and its longest edge is RT_SPH_EDGE units, which leaves half an edge of
-// room on either side for the centres of primitives that reach into the node from outside.
-// Centre and radius are unsigned integers:
-//   8 bits:  one word,  x | y << 8 | z << 16 | r << 24          (four spheres to a 16-byte load)
-//   16 bits: two words, x | y << 16 , z | r << 16               (two spheres to a 16-byte load)
-#ifndef RT_SPH_BITS
-#define RT_SPH_BITS 8
-#endif
-#define RT_SPH_WORDS (RT_SPH_BITS / 8)
-#define RT_SPH_MAX ((1u << RT_SPH_BITS) - 1u)
-#define RT_SPH_EDGE (127u << (RT_SPH_BITS - 8))
-#define RT_SPH_ORG (64u << (RT_SPH_BITS - 8))
-#define RT_SPH_MID (128u << (RT_SPH_BITS - 8))
-#define RT_SPH_SPARE 64          // spare spheres after the last record: a chunk of 64 is read from any record on without clamping
+// Bounding boxes of the records of a node's run, for the kernels' single-precision pre-test.
+// They live in the node's own grid, one byte a coordinate: the node's box starts at RT_SPH_ORG on
+// every axis and its longest edge is RT_SPH_EDGE units, which leaves half an edge of room on either
+// side.  A box is two words, lo.x | lo.y << 8 | lo.z << 16 | hi.x << 24 , hi.y | hi.z << 8
+// (rt_pretest.h); two boxes to a 16-byte load.
+#define RT_SPH_EDGE 127u
+#define RT_SPH_ORG 64u
+#define RT_SPH_SPARE 64          // spare boxes after the last record: a chunk of 64 is read from any record on without clamping
+#define RT_SEG_RECS 16           // records per segment of a run: every segment has a box of its own (the union of its records')
 
 // One Group child as the kernels see it.  The object phase of the closest-hit engine reads
 // this table at wave-uniform addresses (scalar loads); a record carries everything that phase
@@ -49,7 +42,8 @@ struct DevScene {
     const rt_light    *lights;
     const FlatNode    *nodes;      // all meshes' nodes, 64-byte records
     const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
-    const uint32_t    *leaf_sph;   // one packed bounding sphere per leaf_tris record (same index, RT_SPH_WORDS words each)
+    const uint32_t    *leaf_box;   // one packed bounding box per leaf_tris record (same index, two words each)
+    const uint32_t    *seg_box;    // one packed box per segment of a run, at (obj_begin / RT_SEG_RECS) + node index + segment number
     const double      *tri_normals; // normalize(e1 ^ e2) (3 doubles) by global triangle index
     const int32_t     *perlin_p;   // Perlin permutation and unit vectors (perlin_n, 3 x perlin_n); null without Perlin materials
     const double      *perlin_g;

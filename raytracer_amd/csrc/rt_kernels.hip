@@ -292,6 +292,9 @@ __device__ __forceinline__ bool dir_is_regular(V3 d)
 __device__ __forceinline__ bool coord_is_regular(double x) { const double a = fabs(x); return a == 0.0 || (a >= 1e-100 && a <= 1e100); }
 __device__ __forceinline__ bool org_is_regular(V3 e) { return coord_is_regular(e.x) && coord_is_regular(e.y) && coord_is_regular(e.z); }
 
+// slack at either end of a ray's window in the box pre-test, in grid units (see RayB)
+#define RT_BOX_SLACK 4e-3f
+
 struct TravState {
     // ray
     V3 e, d, r;
@@ -439,80 +442,79 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
         T.leaf = child_base == 0;
         if (nd_pad & 1u) run_bt1[tid] = n1;                 // voxel records read it back
-        // the ray for the sphere pre-test: the point where it enters this node's box, in the node's grid
+        // the ray for the box pre-test: the point g where it enters this node's box, in the node's grid, as
+        // c = -g / direction per axis, and the length of its stretch inside the box (see RayB)
         const float sc = __uint_as_float(nd_pad & ~1u);
         const float gx = (float)((e.x + d.x * n0) - lo0) * sc + (float)RT_SPH_ORG, gy = (float)((e.y + d.y * n0) - lo1) * sc + (float)RT_SPH_ORG;
         const float gz = (float)((e.z + d.z * n0) - lo2) * sc + (float)RT_SPH_ORG;
-        const float4 fu = rayf[0][tid], fv = rayf[1][tid];
-        rayf[0][tid].w = -__builtin_fmaf(gx, fu.x, __builtin_fmaf(gy, fu.y, gz * fu.z));
-        rayf[1][tid].w = -__builtin_fmaf(gx, fv.x, __builtin_fmaf(gy, fv.y, gz * fv.z));
+        const float4 fi = rayf[0][tid];
+        const float dlen = rayf[1][tid].w;
+        rayf[1][tid] = make_float4(-(gx * fi.x), -(gy * fi.y), -(gz * fi.z), dlen);
+        rayf[0][tid].w = (float)(n1 - n0) * dlen * sc + RT_BOX_SLACK;
     }
 }
 
-// The sphere pre-test.  A single-precision test of the ray against a record's bounding sphere
-// decides whether the 80-byte record is fetched and the fp64 test made at all.  The spheres are
-// small integers in the grid of the node that owns the run (see RT_SPH_BITS: with 8 bits a sphere
-// is one word and a 16-byte load brings four), rounded outwards at build time.
-// The distance of a sphere's centre c from the ray's line is measured in a frame of the ray: with
-// unit vectors u, v that span the plane perpendicular to the direction, and g a point of the ray,
-//     pu = (c - g).u ,  pv = (c - g).v ,  distance^2 = pu^2 + pv^2
-// -- two short sums of products with no cancellation between large terms (the old form
-// |c - g|^2 - ((c - g).d)^2 / |d|^2 subtracts two numbers of the size of |c - g|^2).  Errors: the
-// entry point g and the direction are rounded to single precision (g <= 256 units: 2e-5; direction
-// 6e-8 rad over at most 450 units: 3e-5), u and v are unit and perpendicular to within 2e-7
-// (1e-4 over 450 units), each sum rounds three products of up to 300 units (1e-4): under 5e-4 grid
-// units in all; RT_SPH_SLACK = 4e-3 units is added to every radius.  So the test only rejects rays
-// that pass the primitive at a clear distance: the fp64 test, which accepts rays within ~1e-15 of
-// the triangle, would reject them too.  A NaN or an overflow anywhere makes the pre-test pass.
-// RayF is the lane's ray for that test: u, v (written whenever the ray's direction changes) and
-// nu = -g.u, nv = -g.v for the point g where the ray enters the node's box, in the node's grid
-// (written when a run opens).
-#define RT_SPH_SLACK (4e-3f * (float)(RT_SPH_EDGE / 127u))
-struct RayF { float ux, uy, uz, nu, vx, vy, vz, nv; };
-__device__ __forceinline__ RayF ray_single(V3 d)
+// The box pre-test.  A single-precision test of the ray against a record's bounding box decides
+// whether the 80-byte record is fetched and the fp64 test made at all; the same test against the
+// box of a whole segment of a run decides whether the segment's records are looked at at all.  The
+// boxes are bytes in the grid of the node that owns the run (rt_pretest.h), rounded outwards by at
+// least 2e-3 grid units at build time, around the part of the primitive inside the node's box.
+// The ray is taken into that grid when the run opens: g = the point where it enters the node's box
+// (at most 256 units from the grid's origin), n = its unit direction; a point of the ray is
+// g + tau * n, and the stretch inside the node's box is 0 <= tau <= tend.  Slab test per axis:
+// tau = (b - g) / n = b * inv + c with inv = 1 / n and c = -g * inv, for b = the box's lower and
+// upper plane; the ray crosses the box inside the window iff
+//     max(min over the planes of every axis, 0) <= min(max over the planes of every axis, tend).
+// Errors, each expressed as the shift of a plane that would have the same effect: g is rounded to
+// single precision (3e-5 units, the arithmetic that forms it included), the direction too (1e-7 rad
+// over at most 450 units: 5e-5), c and the fused multiply-add round once each (6e-8 of at most 450
+// units: 3e-5 each) -- under 2e-4 units in all, a tenth of what the boxes were grown by; the window's
+// ends are off by less than 1e-4 units and RT_BOX_SLACK = 4e-3 units is given at either end.  So the
+// test only rejects rays that pass the primitive's part inside the node at a clear distance: the fp64
+// test, which accepts rays within ~1e-15 of the triangle and only hits inside the window, would
+// reject them too.  A direction component of zero gives inv = inf and tau = NaN for that axis;
+// minima and maxima skip a NaN, so the axis does not constrain the result, and a test whose
+// operands are all NaN passes.
+// RayB is the lane's ray for that test: inv (written whenever the ray's direction changes), c and
+// tend (written when a run opens).
+struct RayB { float ix, iy, iz, tend, cx, cy, cz; };
+struct RayInv { float ix, iy, iz, len; };
+__device__ __forceinline__ RayInv ray_single(V3 d)
 {
     const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz)));
-    const float nx = dx * inv, ny = dy * inv, nz = dz * inv;
-    const float ax = fabsf(nx), ay = fabsf(ny), az = fabsf(nz);
-    // u = (axis of the smallest direction component) x n, normalised: |axis x n|^2 = 1 - n_axis^2 >= 2/3
-    float ux, uy, uz;
-    if (ax <= ay && ax <= az) { ux = 0.0f; uy = -nz; uz = ny; }
-    else if (ay <= az)        { ux = nz; uy = 0.0f; uz = -nx; }
-    else                      { ux = -ny; uy = nx; uz = 0.0f; }
-    const float iu = __builtin_amdgcn_rsqf(__builtin_fmaf(ux, ux, __builtin_fmaf(uy, uy, uz * uz)));
-    ux *= iu; uy *= iu; uz *= iu;
-    RayF r;
-    r.ux = ux; r.uy = uy; r.uz = uz; r.nu = 0.0f;
-    r.vx = ny * uz - nz * uy; r.vy = nz * ux - nx * uz; r.vz = nx * uy - ny * ux; r.nv = 0.0f;       // n x u
+    const float l2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    const float inv = __builtin_amdgcn_rsqf(l2);
+    RayInv r;
+    r.ix = __builtin_amdgcn_rcpf(dx * inv); r.iy = __builtin_amdgcn_rcpf(dy * inv); r.iz = __builtin_amdgcn_rcpf(dz * inv);
+    r.len = l2 * inv;                                   // |d|
     return r;
 }
-struct SphQ { uint32_t w[RT_SPH_WORDS]; };
-__device__ __forceinline__ bool sph_pass(const SphQ &q, const RayF &r)
+__device__ __forceinline__ bool box_pass(uint32_t w0, uint32_t w1, const RayB &r)
 {
-#if RT_SPH_BITS == 8
-    const float sx = (float)(q.w[0] & 255u), sy = (float)((q.w[0] >> 8) & 255u), sz = (float)((q.w[0] >> 16) & 255u), sr = (float)(q.w[0] >> 24);
-#else
-    const float sx = (float)(q.w[0] & 0xFFFFu), sy = (float)(q.w[0] >> 16), sz = (float)(q.w[1] & 0xFFFFu), sr = (float)(q.w[1] >> 16);
-#endif
-    const float pu = __builtin_fmaf(sx, r.ux, __builtin_fmaf(sy, r.uy, __builtin_fmaf(sz, r.uz, r.nu)));
-    const float pv = __builtin_fmaf(sx, r.vx, __builtin_fmaf(sy, r.vy, __builtin_fmaf(sz, r.vz, r.nv)));
-    const float perp2 = __builtin_fmaf(pv, pv, pu * pu);                 // squared distance of the centre from the ray's line
-    const float R = sr + RT_SPH_SLACK;
-    return !(perp2 > R * R);
+    const float lx = (float)(w0 & 255u), ly = (float)((w0 >> 8) & 255u), lz = (float)((w0 >> 16) & 255u), hx = (float)(w0 >> 24);
+    const float hy = (float)(w1 & 255u), hz = (float)((w1 >> 8) & 255u);
+    const float ax = __builtin_fmaf(lx, r.ix, r.cx), bx = __builtin_fmaf(hx, r.ix, r.cx);
+    const float ay = __builtin_fmaf(ly, r.iy, r.cy), by = __builtin_fmaf(hy, r.iy, r.cy);
+    const float az = __builtin_fmaf(lz, r.iz, r.cz), bz = __builtin_fmaf(hz, r.iz, r.cz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), -RT_BOX_SLACK));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), r.tend));
+    return !(tn > tf);
 }
 // ------------------------------------------------------------------ the cooperative triangle phase
 // OctreeNode::hit (octree.cpp:19-38) for every lane of the wave that has a run open (an "owner"),
 // done by the whole wave at once instead of by each lane for itself:
-//   1. segments: every owner cuts its run into segments of RT_SEG records and lists them in the
-//      wave's segment table in LDS (a prefix sum over the owners' segment counts gives each its
-//      place), so that the work of all owners lies in one dense list; a run with a whole chunk of
-//      records or more left gets the table to itself, filled by all lanes at once;
-//   2. pre-test: a chunk = 64 * RT_LANE_RECS / RT_SEG consecutive segments; every lane takes
-//      RT_LANE_RECS consecutive records of its segment, tests their spheres against the segment
-//      owner's ray (read from LDS, where the owner left it when the run opened) and appends
-//      (record, owner) for those that pass to the wave's candidate list in LDS (ballot + count of
-//      the set bits below the lane);
+//   1. segments: every owner cuts its run into segments of RT_SEG records and lists the next ones in
+//      the wave's raw table in LDS (a prefix sum over the owners' segment counts gives each its
+//      place), at most one segment per lane of the wave; a run with a whole chunk of records or more
+//      left gets the round to itself, its segments named by all lanes at once.  Every lane then takes
+//      one listed segment, fetches the segment's box and its owner's ray and makes the box pre-test:
+//      segments that pass go to the wave's work table (ballot + count of the set bits below the
+//      lane), the others -- more than four in five in a typical scene -- are done with.  Rounds
+//      repeat until the work table holds four chunks' worth or the owners have nothing left;
+//   2. pre-test: a chunk = 64 * RT_LANE_RECS / RT_SEG consecutive segments of the work table; every
+//      lane takes RT_LANE_RECS consecutive records of its segment, tests their boxes against the
+//      segment owner's ray (read from LDS, where the owner left it when the run opened) and appends
+//      (record, owner) for those that pass to the wave's candidate list in LDS;
 //   3. test: every lane takes one candidate, fetches its 80-byte record and the owner's fp64 ray
 //      and window (cross-lane reads) and makes the fp64 primitive test -- up to 64 candidates of
 //      different owners per pass;
@@ -521,25 +523,28 @@ __device__ __forceinline__ bool sph_pass(const SphQ &q, const RayF &r)
 //      maximum over list position | id): OctreeNode::hit accepts a hit with `t <= tempt`, so of equal
 //      distances the later primitive wins (octree.cpp:31), and a hit farther than an earlier one
 //      never survives -- the same outcome as testing the owner's candidates one after the other.
-// The wave's cost follows the number of records it serves, not its longest run, and the fp64 tests
-// of all owners share their instructions.
+//      (Candidates of one owner reach the list in run order: rounds, segments and chunks all go
+//      forward through the run.)
+// The wave's cost follows the number of records near its rays, not its longest run, and the fp64
+// tests of all owners share their instructions.
 #ifndef RT_CAND_CAP
 #define RT_CAND_CAP 128          // candidate slots per wave (a ring; a power of two, at least 64)
 #endif
-#ifndef RT_SEG
-#define RT_SEG 16                // records per segment (a power of two, at most 64)
-#endif
-#define RT_LANE_RECS 4           // records a lane pre-tests per chunk (their spheres are one 16-byte load)
-#ifndef RT_SEG_CAP
-#define RT_SEG_CAP 128           // segment table entries per wave, one of them the empty entry: (RT_SEG_CAP - 1) * RT_SEG records are scheduled per round
-#endif
+#define RT_SEG RT_SEG_RECS       // records per segment (a power of two, at most 64)
+#define RT_LANE_RECS 4           // records a lane pre-tests per chunk (their boxes are two 16-byte loads)
+#define RT_SEG_CAP 128           // work table entries per wave, one of them the empty entry: a round adds at most 64 to fewer than 64
 #define RT_SEG_ROUND_MAX 15      // most segments one owner lists per round (4 bits in the prefix sum)
 struct CoopLds {                 // per wave
-    uint64_t seg[RT_SEG_CAP];    // first record | owner lane << 32 | records in the segment << 40; behind the last one an empty entry
+    uint64_t seg[RT_SEG_CAP];    // work table: first record | owner lane << 32 | records in the segment << 40; behind the last one an empty entry
     uint32_t crec[RT_CAND_CAP];  // candidate's record index
     uint8_t  cown[RT_CAND_CAP];  // candidate's owner lane
-    unsigned long long okey[64]; // per owner lane, per pass: smallest hit distance as an ordered integer
-    unsigned long long owin[64]; //   (list position + 1) << 32 | primitive id of the last candidate that reached it
+    union {
+        struct {
+            unsigned long long okey[64]; // per owner lane, per pass: smallest hit distance as an ordered integer
+            unsigned long long owin[64]; //   (list position + 1) << 32 | primitive id of the last candidate that reached it
+        };
+        uint64_t raw[64];        // raw table of a round (entries as in seg); no fp64 pass runs while it is in use
+    };
 };
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 // the lanes for which p holds, as a mask (the predicate's own lane mask: no 0/1 value is formed)
@@ -564,17 +569,17 @@ template <int BLOCK>
 __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &mode, const double *run_bt1,
                                           const float4 (*rayf)[BLOCK], CoopLds &L, Counters &c)
 {
-    static_assert(RT_SPH_WORDS == 1, "one word per sphere: a chunk's spheres are one dword per lane");
     static_assert((RT_CAND_CAP & (RT_CAND_CAP - 1)) == 0 && RT_CAND_CAP >= 64, "candidate ring");
     static_assert((RT_SEG & (RT_SEG - 1)) == 0 && RT_SEG <= 64 && RT_SEG <= RT_SPH_SPARE, "segment size");
     // a chunk = RT_LANE_RECS consecutive records per lane, RT_SEG / RT_LANE_RECS lanes to a segment
     constexpr uint32_t LANES_PER_SEG = RT_SEG / RT_LANE_RECS, SEGS_PER_CHUNK = 64u / LANES_PER_SEG;
-    static_assert(RT_LANE_RECS == 4 && RT_SEG % RT_LANE_RECS == 0, "a lane's spheres are one 16-byte load");
+    static_assert(RT_LANE_RECS == 4 && RT_SEG % RT_LANE_RECS == 0, "a lane's boxes are two 16-byte loads");
     const uint32_t lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
     const uint32_t sub = (lane % LANES_PER_SEG) * RT_LANE_RECS, sseg = lane / LANES_PER_SEG;     // the lane's place in a chunk
     uint32_t produced = 0, tested = 0;                 // candidates appended / tested so far (wave-uniform)
     const bool owner = mode == TM_TRI;
     uint32_t kcur = T.k;                               // first record of the owner's run that is not scheduled yet
+    const uint32_t segbase = T.k / RT_SEG + T.cur;     // where the boxes of the owner's segments start (DevScene::seg_box)
 
 #if RT_STEP_STATS == 8 || RT_STEP_STATS == 9
     long long tk8 = clock64();
@@ -664,64 +669,31 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
         RT_TICK8(leaf)
     };
 
-    for (;;) {
-        // ---- step 1: the next job = the segment table of this round.  An owner with at least a whole
-        // chunk of records left takes the wave for itself: its whole chunks are listed by all lanes at
-        // once (segment i starts at base + i * RT_SEG).  Otherwise every owner lists the next segments
-        // of its run, each at its place in a prefix sum over the owners' segment counts.
-        constexpr uint32_t CHUNK_RECS = 64u * RT_LANE_RECS, SOLO_CHUNKS = (RT_SEG_CAP - 1u) / SEGS_PER_CHUNK;
-        const uint32_t left = owner ? T.kend - kcur : 0u;
-        const unsigned long long big = ballot64(left >= CHUNK_RECS);
-        uint32_t total = 0;
-        if (big != 0ull) {
-            const uint32_t solo_o = (uint32_t)__ffsll((long long)big) - 1u;
-            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)kcur, (int)solo_o);
-            uint32_t nch = ((uint32_t)__builtin_amdgcn_readlane((int)T.kend, (int)solo_o) - base) / CHUNK_RECS;
-            if (nch > SOLO_CHUNKS) nch = SOLO_CHUNKS;
-            total = nch * SEGS_PER_CHUNK;
-#pragma unroll
-            for (uint32_t i = lane; i < SOLO_CHUNKS * SEGS_PER_CHUNK; i += 64u)
-                if (i < total) L.seg[i] = (unsigned long long)(base + i * RT_SEG) | ((unsigned long long)solo_o << 32) | ((unsigned long long)RT_SEG << 40);
-            if (lane == solo_o) kcur += nch * CHUNK_RECS;
-        } else {
-            uint32_t nseg = (left + (RT_SEG - 1u)) / RT_SEG;
-            if (nseg > (uint32_t)RT_SEG_ROUND_MAX) nseg = RT_SEG_ROUND_MAX;
-            const unsigned long long b0 = ballot64((nseg & 1u) != 0u), b1 = ballot64((nseg & 2u) != 0u), b2 = ballot64((nseg & 4u) != 0u), b3 = ballot64((nseg & 8u) != 0u);
-            uint32_t first = count_below(b0, 0u) + 2u * count_below(b1, 0u) + 4u * count_below(b2, 0u) + 8u * count_below(b3, 0u);
-            total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
-            if (total == 0u) break;
-            RT_TICK9(rays)
-            if (total > (uint32_t)RT_SEG_CAP - 1u) total = RT_SEG_CAP - 1u;        // the rest waits for the next round
-            if (first > total) first = total;
-            if (nseg > total - first) nseg = total - first;
-#pragma unroll 1
-            for (uint32_t j = 0; j < (uint32_t)RT_SEG_ROUND_MAX; j++) {
-                if (ballot64(j < nseg) == 0ull) break;
-                if (j < nseg) {
-                    const uint32_t r0 = kcur + j * RT_SEG, cnt = T.kend - r0 < (uint32_t)RT_SEG ? T.kend - r0 : (uint32_t)RT_SEG;
-                    L.seg[first + j] = (unsigned long long)r0 | ((unsigned long long)lane << 32) | ((unsigned long long)cnt << 40);
-                }
-            }
-            if (nseg) { const uint32_t adv = nseg * RT_SEG; kcur = T.kend - kcur < adv ? T.kend : kcur + adv; }
-            RT_TICK9(inner)
-        }
+    auto ray_of = [&](uint32_t o) -> RayB {
+        const float4 a_ = rayf[0][wave0 + o], b_ = rayf[1][wave0 + o];
+        RayB r;
+        r.ix = a_.x; r.iy = a_.y; r.iz = a_.z; r.tend = a_.w; r.cx = b_.x; r.cy = b_.y; r.cz = b_.z;
+        return r;
+    };
+    // ---- step 2: the work table's segments, pre-tested chunk by chunk.  A lane takes RT_LANE_RECS
+    // consecutive records of its segment (two 16-byte loads bring their boxes, two LDS reads the
+    // owner's ray).  A chunk's segment entry is read from LDS two chunks ahead, its boxes and its
+    // owner's ray are requested one chunk ahead of their use, unconditionally (past the last segment:
+    // the empty entry), so that nothing a chunk's tests wait for was requested in the same iteration.
+    // Nothing else is loaded inside the loop: when the candidate ring cannot take a chunk's
+    // candidates the loop is left, the ring emptied by an fp64 pass, and the loop entered again.
+    auto run_chunks = [&](const uint32_t total) {
         if (lane == 0) L.seg[total] = 0ull;                                         // what a chunk reads past the last segment: no records
         const uint32_t nchunk = (total + SEGS_PER_CHUNK - 1u) / SEGS_PER_CHUNK;
-        // ---- step 2: pre-test chunk by chunk.  A lane takes RT_LANE_RECS consecutive records of its
-        // segment (one 16-byte load brings their spheres, one LDS read the owner's ray).  A chunk's
-        // segment entry is read from LDS two chunks ahead, its spheres and its owner's ray are
-        // requested one chunk ahead of their use, unconditionally (past the last segment: the empty
-        // entry), so that nothing a chunk's tests wait for was requested in the same iteration.
-        // Nothing else is loaded inside the loop: when the candidate ring cannot take a chunk's
-        // candidates the loop is left, the ring emptied by an fp64 pass, and the loop entered again.
         RT_TICK8(rays)
         auto entry = [&](uint32_t ch) -> unsigned long long {
             const uint32_t sidx = ch * SEGS_PER_CHUNK + sseg;
             return L.seg[sidx < total ? sidx : total];
         };
-        auto spheres = [&](unsigned long long e) -> uint4 {
-            uint4 v;
-            __builtin_memcpy(&v, S.leaf_sph + ((uint32_t)e + sub), 16);       // aligned to a sphere's size only
+        struct Boxes { uint4 a, b; };
+        auto boxes = [&](unsigned long long e) -> Boxes {
+            Boxes v;
+            __builtin_memcpy(&v, S.leaf_box + 2ull * ((uint32_t)e + sub), 32);       // aligned to a box's size only
             return v;
         };
         // Candidates in list order: lane by lane, a lane's records in order.  Of a chunk's candidates
@@ -758,30 +730,27 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
         };
         uint32_t ch = 0;
         while (ch < nchunk) {
-            // the chunk in hand, and the next one: its entry has been read, its spheres are requested
+            // the chunk in hand, and the next one: its entry has been read, its boxes are requested
             // at the top of the iteration before its own (only while there is a next chunk: a load
             // that nobody waits for would hold up whoever reuses its register)
             unsigned long long e0 = entry(ch), e1 = entry(ch + 1u), held_m[RT_LANE_RECS], held_e = 0ull;
-            uint4 sp0 = spheres(e0), sp1 = sp0;
-            float4 ru0 = rayf[0][wave0 + ((uint32_t)(e0 >> 32) & 0xFFu)], rv0 = rayf[1][wave0 + ((uint32_t)(e0 >> 32) & 0xFFu)];
+            Boxes bx0 = boxes(e0), bx1 = bx0;
+            RayB rf0 = ray_of((uint32_t)(e0 >> 32) & 0xFFu);
             bool held = false;
             uint32_t held_n = 0;
             for (; ch < nchunk; ch++) {
-                if (ch + 1u < nchunk) sp1 = spheres(e1);
+                if (ch + 1u < nchunk) bx1 = boxes(e1);
                 const unsigned long long e2 = entry(ch + 2u);
-                const uint32_t o1 = (uint32_t)(e1 >> 32) & 0xFFu, cnt = (uint32_t)(e0 >> 40);
-                const float4 ru1 = rayf[0][wave0 + o1], rv1 = rayf[1][wave0 + o1];     // the next chunk's ray
-                const float4 a_ = ru0, b_ = rv0;
-                RayF rf;
-                rf.ux = a_.x; rf.uy = a_.y; rf.uz = a_.z; rf.nu = a_.w; rf.vx = b_.x; rf.vy = b_.y; rf.vz = b_.z; rf.nv = b_.w;
-                const uint32_t w[RT_LANE_RECS] = { sp0.x, sp0.y, sp0.z, sp0.w };
+                const uint32_t cnt = (uint32_t)(e0 >> 40);
+                const RayB rf1 = ray_of((uint32_t)(e1 >> 32) & 0xFFu);           // the next chunk's ray
+                const RayB rf = rf0;
+                const uint32_t w[RT_LANE_RECS][2] = { { bx0.a.x, bx0.a.y }, { bx0.a.z, bx0.a.w }, { bx0.b.x, bx0.b.y }, { bx0.b.z, bx0.b.w } };
                 unsigned long long m[RT_LANE_RECS];
                 bool p[RT_LANE_RECS];
                 uint32_t np = 0;
 #pragma unroll
                 for (int r = 0; r < RT_LANE_RECS; r++) {
-                    SphQ q; q.w[0] = w[r];
-                    const bool in_seg = sub + (uint32_t)r < cnt, near = sph_pass(q, rf);
+                    const bool in_seg = sub + (uint32_t)r < cnt, near = box_pass(w[r][0], w[r][1], rf);
                     p[r] = in_seg & near;
                     m[r] = ballot64(in_seg) & ballot64(near);                     // two compare masks and a scalar AND
                     np += (uint32_t)__popcll(m[r]);
@@ -798,7 +767,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                 }
                 append(m, p, e0);
                 produced += np;
-                e0 = e1; e1 = e2; sp0 = sp1; ru0 = ru1; rv0 = rv1;
+                e0 = e1; e1 = e2; bx0 = bx1; rf0 = rf1;
             }
             if (held) {
                 // an fp64 pass empties the ring; a chunk with more candidates than the ring holds goes in pieces
@@ -810,7 +779,72 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                 }
             }
         }
+    };
+
+    // ---- step 1: rounds.  An owner with at least a whole chunk of records left takes the round for
+    // itself: its next whole segments are named by all lanes at once (lane i: base + i * RT_SEG).
+    // Otherwise every owner lists the next segments of its run in the raw table, each at its place
+    // in a prefix sum over the owners' segment counts, and every lane reads one entry back.  Then
+    // the segments' own box test; what passes moves on to the work table.
+    uint32_t work_n = 0;                               // entries in the work table (wave-uniform)
+    for (;;) {
+        constexpr uint32_t CHUNK_RECS = 64u * RT_LANE_RECS;
+        const uint32_t left = owner ? T.kend - kcur : 0u;
+        const unsigned long long big = ballot64(left >= CHUNK_RECS);
+        uint32_t total = 0;
+        unsigned long long rawe = 0ull;
+        if (big != 0ull) {
+            const uint32_t solo_o = (uint32_t)__ffsll((long long)big) - 1u;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)kcur, (int)solo_o);
+            total = ((uint32_t)__builtin_amdgcn_readlane((int)T.kend, (int)solo_o) - base) / RT_SEG;
+            if (total > 64u) total = 64u;
+            if (lane < total) rawe = (unsigned long long)(base + lane * RT_SEG) | ((unsigned long long)solo_o << 32) | ((unsigned long long)RT_SEG << 40);
+            if (lane == solo_o) kcur += total * RT_SEG;
+        } else {
+            uint32_t nseg = (left + (RT_SEG - 1u)) / RT_SEG;
+            if (nseg > (uint32_t)RT_SEG_ROUND_MAX) nseg = RT_SEG_ROUND_MAX;
+            const unsigned long long b0 = ballot64((nseg & 1u) != 0u), b1 = ballot64((nseg & 2u) != 0u), b2 = ballot64((nseg & 4u) != 0u), b3 = ballot64((nseg & 8u) != 0u);
+            uint32_t first = count_below(b0, 0u) + 2u * count_below(b1, 0u) + 4u * count_below(b2, 0u) + 8u * count_below(b3, 0u);
+            total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2) + 8u * (uint32_t)__popcll(b3);
+            if (total == 0u) break;
+            RT_TICK9(rays)
+            if (total > 64u) total = 64u;                                            // the rest waits for the next round
+            if (first > total) first = total;
+            if (nseg > total - first) nseg = total - first;
+#pragma unroll 1
+            for (uint32_t j = 0; j < (uint32_t)RT_SEG_ROUND_MAX; j++) {
+                if (ballot64(j < nseg) == 0ull) break;
+                if (j < nseg) {
+                    const uint32_t r0 = kcur + j * RT_SEG, cnt = T.kend - r0 < (uint32_t)RT_SEG ? T.kend - r0 : (uint32_t)RT_SEG;
+                    L.raw[first + j] = (unsigned long long)r0 | ((unsigned long long)lane << 32) | ((unsigned long long)cnt << 40);
+                }
+            }
+            if (nseg) { const uint32_t adv = nseg * RT_SEG; kcur = T.kend - kcur < adv ? T.kend : kcur + adv; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < total) rawe = L.raw[lane];
+            __builtin_amdgcn_wave_barrier();
+            RT_TICK9(inner)
+        }
+        {
+            // the segment's box against its owner's ray
+            const bool have = lane < total;
+            const uint32_t so = (uint32_t)(rawe >> 32) & 0xFFu;
+            const uint32_t obase = (uint32_t)__shfl((int)segbase, (int)so, 64), ok = (uint32_t)__shfl((int)T.k, (int)so, 64);
+            const uint32_t sidx = have ? obase + ((uint32_t)rawe - ok) / RT_SEG : 0u;
+            uint2 sb;
+            __builtin_memcpy(&sb, S.seg_box + 2ull * sidx, 8);
+            const RayB rf = ray_of(so);
+            const bool pass = have && box_pass(sb.x, sb.y, rf);
+            const unsigned long long pm = ballot64(pass);
+            if (pass) L.seg[count_below(pm, work_n)] = rawe;
+            work_n += (uint32_t)__popcll(pm);
+#if RT_STEP_STATS == 7
+            if (lane == 0) { c.rays += total; }                 // segments listed
+#endif
+        }
+        if (work_n >= 64u) { run_chunks(work_n); work_n = 0; }
     }
+    if (work_n) run_chunks(work_n);
     RT_TICK9(leaf)
     test_all();
     RT_TICK8(rays)
@@ -850,11 +884,11 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total = src.count();
     __shared__ double run_bt1[BLOCK];        // upper end of the window of the lane's current primitive run
-    // the lane's ray for the sphere pre-test (see RayF), read back by the triangle phase: u and v
-    // and 1/|d|^2 are formed whenever T.d changes, the entry point and its slack when a run opens
-    // (node_step)
+    // the lane's ray for the box pre-test (see RayB), read back by the triangle phase: 1 / direction and
+    // |d| are formed whenever T.d changes, the entry point and the window's length when a run opens
+    // (node_step).  rayf[0] = {inv.x, inv.y, inv.z, tend}, rayf[1] = {c.x, c.y, c.z, |d|}
     __shared__ float4 rayf[2][BLOCK];
-#define RT_RAYF_PUT() { const RayF q_ = ray_single(T.d); rayf[0][tid] = make_float4(q_.ux, q_.uy, q_.uz, 0.0f); rayf[1][tid] = make_float4(q_.vx, q_.vy, q_.vz, 0.0f); }
+#define RT_RAYF_PUT() { const RayInv q_ = ray_single(T.d); rayf[0][tid] = make_float4(q_.ix, q_.iy, q_.iz, 0.0f); rayf[1][tid] = make_float4(0.0f, 0.0f, 0.0f, q_.len); }
     __shared__ CoopLds coop[BLOCK / 64];      // the wave's candidate list of the cooperative triangle phase
     // Three blocks of 256 lanes share a CU's 160 KB only while a block asks for no more than 53760
     // bytes (the allocation is rounded up in steps that 53760 exactly fills): 32 bytes more and a
