@@ -404,6 +404,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     // a whole segment from any record on.
     std::vector<uint32_t> leaf_box((leaf_tris.size() + RT_SPH_SPARE) * 2);
     std::vector<uint32_t> seg_box((leaf_tris.size() / RT_SEG_RECS + nodes.size() + 2) * 2);
+    std::vector<uint32_t> run_box(nodes.size() * 2 + 2);          // per node: the union of its run's boxes
     for (size_t i = 0; i < leaf_box.size() / 2; i++) store_whole_node_box(&leaf_box[2 * i]);
     for (size_t i = 0; i < seg_box.size() / 2; i++) store_whole_node_box(&seg_box[2 * i]);
     for (size_t ni = 0; ni < nodes.size(); ni++) {
@@ -413,6 +414,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         std::memcpy(&bits, &scale, 4);
         n.pad = bits | (n.pad & 1u);                  // grid scale, voxel flag in the lowest bit
         const size_t seg0 = (size_t)(n.obj_begin / RT_SEG_RECS) + ni;
+        int rlo[3] = {256, 256, 256}, rhi[3] = {-1, -1, -1};
         for (uint32_t j = 0; j < n.obj_count; j += RT_SEG_RECS) {
             int ulo[3] = {256, 256, 256}, uhi[3] = {-1, -1, -1};
             for (uint32_t i = n.obj_begin + j; i < n.obj_begin + n.obj_count && i < n.obj_begin + j + RT_SEG_RECS; i++) {
@@ -422,16 +424,18 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
                 for (int k = 0; k < 3; k++) { if (lo[k] < ulo[k]) ulo[k] = lo[k]; if (hi[k] > uhi[k]) uhi[k] = hi[k]; }
             }
             store_grid_box(&seg_box[(seg0 + j / RT_SEG_RECS) * 2], ulo, uhi);
+            for (int k = 0; k < 3; k++) { if (ulo[k] < rlo[k]) rlo[k] = ulo[k]; if (uhi[k] > rhi[k]) rhi[k] = uhi[k]; }
         }
+        store_grid_box(&run_box[ni * 2], rlo, rhi);
     }
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
-    void *p_pp = nullptr, *p_pg = nullptr, *p_seg = nullptr;
+    void *p_pp = nullptr, *p_pg = nullptr, *p_seg = nullptr, *p_run = nullptr;
     auto up = [&](auto &vec, void **dst) {
         if (e != hipSuccess) return;
         e = upload(vec, dst);
         if (*dst) s->allocs.push_back(*dst);
     };
-    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tri_normals, &p_tris); up(leaf_box, &p_sph); up(seg_box, &p_seg);
+    up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tri_normals, &p_tris); up(leaf_box, &p_sph); up(seg_box, &p_seg); up(run_box, &p_run);
     up(perlin_p, &p_pp); up(perlin_g, &p_pg);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
@@ -443,6 +447,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.leaf_tris = (const LeafTri *)p_idx;
     s->dev.leaf_box = (const uint32_t *)p_sph;
     s->dev.seg_box = (const uint32_t *)p_seg;
+    s->dev.run_box = (const uint32_t *)p_run;
     s->dev.tri_normals = (const double *)p_tris;
     s->dev.perlin_p = (const int32_t *)p_pp;
     s->dev.perlin_g = (const double *)p_pg;

@@ -43,6 +43,7 @@ struct DevScene {
     const FlatNode    *nodes;      // all meshes' nodes, 64-byte records
     const LeafTri     *leaf_tris;  // per-node triangle runs (80-byte records, id = global triangle index)
     const uint32_t    *leaf_box;   // one packed bounding box per leaf_tris record (same index, two words each)
+    const uint32_t    *run_box;    // one packed box per node (two words, by node index): the union of the boxes of its run
     const uint32_t    *seg_box;    // one packed box per segment of a run, at (obj_begin / RT_SEG_RECS) + node index + segment number
     const double      *tri_normals; // normalize(e1 ^ e2) (3 doubles) by global triangle index
     const int32_t     *perlin_p;   // Perlin permutation and unit vectors (perlin_n, 3 x perlin_n); null without Perlin materials

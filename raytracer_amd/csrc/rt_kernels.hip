@@ -292,8 +292,53 @@ __device__ __forceinline__ bool dir_is_regular(V3 d)
 __device__ __forceinline__ bool coord_is_regular(double x) { const double a = fabs(x); return a == 0.0 || (a >= 1e-100 && a <= 1e100); }
 __device__ __forceinline__ bool org_is_regular(V3 e) { return coord_is_regular(e.x) && coord_is_regular(e.y) && coord_is_regular(e.z); }
 
-// slack at either end of a ray's window in the box pre-test, in grid units (see RayB)
+// The box pre-test.  A single-precision test of the ray against a record's bounding box decides
+// whether the 80-byte record is fetched and the fp64 test made at all; the same test against the
+// box of a whole segment of a run decides whether the segment's records are looked at at all.  The
+// boxes are bytes in the grid of the node that owns the run (rt_pretest.h), rounded outwards by at
+// least 2e-3 grid units at build time, around the part of the primitive inside the node's box.
+// The ray is taken into that grid when the run opens: g = the point where it enters the node's box
+// (at most 256 units from the grid's origin), n = its unit direction; a point of the ray is
+// g + tau * n, and the stretch inside the node's box is 0 <= tau <= tend.  Slab test per axis:
+// tau = (b - g) / n = b * inv + c with inv = 1 / n and c = -g * inv, for b = the box's lower and
+// upper plane; the ray crosses the box inside the window iff
+//     max(min over the planes of every axis, 0) <= min(max over the planes of every axis, tend).
+// Errors, each expressed as the shift of a plane that would have the same effect: g is rounded to
+// single precision (3e-5 units, the arithmetic that forms it included), the direction too (1e-7 rad
+// over at most 450 units: 5e-5), c and the fused multiply-add round once each (6e-8 of at most 450
+// units: 3e-5 each) -- under 2e-4 units in all, a tenth of what the boxes were grown by; the window's
+// ends are off by less than 1e-4 units and RT_BOX_SLACK = 4e-3 units is given at either end.  So the
+// test only rejects rays that pass the primitive's part inside the node at a clear distance: the fp64
+// test, which accepts rays within ~1e-15 of the triangle and only hits inside the window, would
+// reject them too.  A direction component of zero gives inv = inf and tau = NaN for that axis;
+// minima and maxima skip a NaN, so the axis does not constrain the result, and a test whose
+// operands are all NaN passes.
+// RayB is the lane's ray for that test: inv (written whenever the ray's direction changes), c and
+// tend (written when a run opens).
 #define RT_BOX_SLACK 4e-3f
+struct RayB { float ix, iy, iz, tend, cx, cy, cz; };
+struct RayInv { float ix, iy, iz, len; };
+__device__ __forceinline__ RayInv ray_single(V3 d)
+{
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const float l2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    const float inv = __builtin_amdgcn_rsqf(l2);
+    RayInv r;
+    r.ix = __builtin_amdgcn_rcpf(dx * inv); r.iy = __builtin_amdgcn_rcpf(dy * inv); r.iz = __builtin_amdgcn_rcpf(dz * inv);
+    r.len = l2 * inv;                                   // |d|
+    return r;
+}
+__device__ __forceinline__ bool box_pass(uint32_t w0, uint32_t w1, const RayB &r)
+{
+    const float lx = (float)(w0 & 255u), ly = (float)((w0 >> 8) & 255u), lz = (float)((w0 >> 16) & 255u), hx = (float)(w0 >> 24);
+    const float hy = (float)(w1 & 255u), hz = (float)((w1 >> 8) & 255u);
+    const float ax = __builtin_fmaf(lx, r.ix, r.cx), bx = __builtin_fmaf(hx, r.ix, r.cx);
+    const float ay = __builtin_fmaf(ly, r.iy, r.cy), by = __builtin_fmaf(hy, r.iy, r.cy);
+    const float az = __builtin_fmaf(lz, r.iz, r.cz), bz = __builtin_fmaf(hz, r.iz, r.cz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), -RT_BOX_SLACK));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), r.tend));
+    return !(tn > tf);
+}
 
 struct TravState {
     // ray
@@ -352,6 +397,8 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     const double lo0 = nd->lo[0], lo1 = nd->lo[1], lo2 = nd->lo[2];
     const double hi0 = nd->hi[0], hi1 = nd->hi[1], hi2 = nd->hi[2];
     const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count, nd_pad = nd->pad;
+    uint2 run_box;                                          // around everything in the node's run (asked for together with the node)
+    __builtin_memcpy(&run_box, S.run_box + 2ull * T.cur, 8);
     // per-axis plane distances; the node's own slab test and all 8 child tests use them
     const double al0 = qdiv<FAST>(lo0 - e.x, d.x, r.x), al1 = qdiv<FAST>(lo1 - e.y, d.y, r.y), al2 = qdiv<FAST>(lo2 - e.z, d.z, r.z);
     const double ah0 = qdiv<FAST>(hi0 - e.x, d.x, r.x), ah1 = qdiv<FAST>(hi1 - e.y, d.y, r.y), ah2 = qdiv<FAST>(hi2 - e.z, d.z, r.z);
@@ -437,11 +484,6 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         }
     }
     if (hb && obj_count) {                                  // OctreeNode::hit, octree.cpp:19-38
-        mode = TM_TRI;
-        T.k = obj_begin; T.kend = obj_begin + obj_count;
-        T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
-        T.leaf = child_base == 0;
-        if (nd_pad & 1u) run_bt1[tid] = n1;                 // voxel records read it back
         // the ray for the box pre-test: the point g where it enters this node's box, in the node's grid, as
         // c = -g / direction per axis, and the length of its stretch inside the box (see RayB)
         const float sc = __uint_as_float(nd_pad & ~1u);
@@ -449,57 +491,28 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         const float gz = (float)((e.z + d.z * n0) - lo2) * sc + (float)RT_SPH_ORG;
         const float4 fi = rayf[0][tid];
         const float dlen = rayf[1][tid].w;
-        rayf[1][tid] = make_float4(-(gx * fi.x), -(gy * fi.y), -(gz * fi.z), dlen);
-        rayf[0][tid].w = (float)(n1 - n0) * dlen * sc + RT_BOX_SLACK;
+        RayB rb;
+        rb.ix = fi.x; rb.iy = fi.y; rb.iz = fi.z;
+        rb.cx = -(gx * fi.x); rb.cy = -(gy * fi.y); rb.cz = -(gz * fi.z);
+        rb.tend = (float)(n1 - n0) * dlen * sc + RT_BOX_SLACK;
+        if (!box_pass(run_box.x, run_box.y, rb)) {
+            // the ray passes everything in this run at a distance: the run is covered without a look at
+            // its records (mode stays TM_POP: nothing was hit here)
+#if !defined(RT_STEP_STATS)
+            c.prim += obj_count;
+#endif
+            return;
+        }
+        mode = TM_TRI;
+        T.k = obj_begin; T.kend = obj_begin + obj_count;
+        T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
+        T.leaf = child_base == 0;
+        if (nd_pad & 1u) run_bt1[tid] = n1;                 // voxel records read it back
+        rayf[1][tid] = make_float4(rb.cx, rb.cy, rb.cz, dlen);
+        rayf[0][tid].w = rb.tend;
     }
 }
 
-// The box pre-test.  A single-precision test of the ray against a record's bounding box decides
-// whether the 80-byte record is fetched and the fp64 test made at all; the same test against the
-// box of a whole segment of a run decides whether the segment's records are looked at at all.  The
-// boxes are bytes in the grid of the node that owns the run (rt_pretest.h), rounded outwards by at
-// least 2e-3 grid units at build time, around the part of the primitive inside the node's box.
-// The ray is taken into that grid when the run opens: g = the point where it enters the node's box
-// (at most 256 units from the grid's origin), n = its unit direction; a point of the ray is
-// g + tau * n, and the stretch inside the node's box is 0 <= tau <= tend.  Slab test per axis:
-// tau = (b - g) / n = b * inv + c with inv = 1 / n and c = -g * inv, for b = the box's lower and
-// upper plane; the ray crosses the box inside the window iff
-//     max(min over the planes of every axis, 0) <= min(max over the planes of every axis, tend).
-// Errors, each expressed as the shift of a plane that would have the same effect: g is rounded to
-// single precision (3e-5 units, the arithmetic that forms it included), the direction too (1e-7 rad
-// over at most 450 units: 5e-5), c and the fused multiply-add round once each (6e-8 of at most 450
-// units: 3e-5 each) -- under 2e-4 units in all, a tenth of what the boxes were grown by; the window's
-// ends are off by less than 1e-4 units and RT_BOX_SLACK = 4e-3 units is given at either end.  So the
-// test only rejects rays that pass the primitive's part inside the node at a clear distance: the fp64
-// test, which accepts rays within ~1e-15 of the triangle and only hits inside the window, would
-// reject them too.  A direction component of zero gives inv = inf and tau = NaN for that axis;
-// minima and maxima skip a NaN, so the axis does not constrain the result, and a test whose
-// operands are all NaN passes.
-// RayB is the lane's ray for that test: inv (written whenever the ray's direction changes), c and
-// tend (written when a run opens).
-struct RayB { float ix, iy, iz, tend, cx, cy, cz; };
-struct RayInv { float ix, iy, iz, len; };
-__device__ __forceinline__ RayInv ray_single(V3 d)
-{
-    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-    const float l2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-    const float inv = __builtin_amdgcn_rsqf(l2);
-    RayInv r;
-    r.ix = __builtin_amdgcn_rcpf(dx * inv); r.iy = __builtin_amdgcn_rcpf(dy * inv); r.iz = __builtin_amdgcn_rcpf(dz * inv);
-    r.len = l2 * inv;                                   // |d|
-    return r;
-}
-__device__ __forceinline__ bool box_pass(uint32_t w0, uint32_t w1, const RayB &r)
-{
-    const float lx = (float)(w0 & 255u), ly = (float)((w0 >> 8) & 255u), lz = (float)((w0 >> 16) & 255u), hx = (float)(w0 >> 24);
-    const float hy = (float)(w1 & 255u), hz = (float)((w1 >> 8) & 255u);
-    const float ax = __builtin_fmaf(lx, r.ix, r.cx), bx = __builtin_fmaf(hx, r.ix, r.cx);
-    const float ay = __builtin_fmaf(ly, r.iy, r.cy), by = __builtin_fmaf(hy, r.iy, r.cy);
-    const float az = __builtin_fmaf(lz, r.iz, r.cz), bz = __builtin_fmaf(hz, r.iz, r.cz);
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), -RT_BOX_SLACK));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), r.tend));
-    return !(tn > tf);
-}
 // ------------------------------------------------------------------ the cooperative triangle phase
 // OctreeNode::hit (octree.cpp:19-38) for every lane of the wave that has a run open (an "owner"),
 // done by the whole wave at once instead of by each lane for itself:
@@ -838,19 +851,31 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             const unsigned long long pm = ballot64(pass);
             if (pass) L.seg[count_below(pm, work_n)] = rawe;
             work_n += (uint32_t)__popcll(pm);
-#if RT_STEP_STATS == 7
-            if (lane == 0) { c.rays += total; }                 // segments listed
+#if RT_STEP_STATS == 10
+            if (lane == 0) { c.rays += 1; c.inner += total; c.leaf += (uint32_t)__popcll(pm); }      // rounds, segments listed, segments that pass
 #endif
         }
-        if (work_n >= 64u) { run_chunks(work_n); work_n = 0; }
+        RT_TICK9(leaf)
+        if (work_n >= 64u) {
+#if RT_STEP_STATS == 10
+            if (lane == 0) c.prim += 1;                         // passes over the work table
+#endif
+            run_chunks(work_n); work_n = 0;
+            RT_TICK9(prim)
+        }
     }
-    if (work_n) run_chunks(work_n);
-    RT_TICK9(leaf)
+    if (work_n) {
+#if RT_STEP_STATS == 10
+        if (lane == 0) c.prim += 1;
+#endif
+        run_chunks(work_n);
+    }
+    RT_TICK9(prim)
     test_all();
     RT_TICK8(rays)
     RT_TICK9(prim)
     if (owner) {
-#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9
+#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9 && RT_STEP_STATS != 10
         c.prim += T.kend - T.k;
 #endif
         bool improved = false;

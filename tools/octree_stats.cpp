@@ -86,32 +86,26 @@ static bool clipped_box(const LeafTri &t, const FlatNode &n, double lo[3], doubl
 }
 
 struct Pre {            // per record
-    double sc[3], sr;   // sphere as the 8-bit grid stores it, back in scene units
-    double xc[3], xr;   // exact clipped sphere
-    double blo[3], bhi[3];   // clipped box, exact
     double qlo[3], qhi[3];   // clipped box in the 8-bit grid, rounded outwards, back in scene units
-    double q16lo[3], q16hi[3];
     bool empty;
 };
-struct Tree { FlatTree ft; std::vector<Pre> pre; std::vector<int> depth; };
+struct Tree { FlatTree ft; std::vector<Pre> pre; std::vector<int> depth; std::vector<uint32_t> sorted; };   // sorted: per run, record indices in Morton order
 
-static bool line_sphere(V e, V d, const double c[3], double r)
-{
-    V oc{c[0] - e.x, c[1] - e.y, c[2] - e.z};
-    const double dd = dot(d, d), od = dot(oc, d);
-    const double perp2 = dot(oc, oc) - od * od / dd;
-    return perp2 <= r * r;
-}
 static bool ray_box_window(V e, V d, const double *lo, const double *hi, double t0, double t1)
 {
     double r0, r1;
     return hit_box(lo, hi, e, d, t0, t1, r0, r1);
 }
+static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t m = 0;
+    for (int b = 0; b < 8; b++) m |= ((x >> b) & 1u) << (3 * b) | ((y >> b) & 1u) << (3 * b + 1) | ((z >> b) & 1u) << (3 * b + 2);
+    return m;
+}
 
 struct Stats {
-    double visits = 0, recs = 0, s8 = 0, sx = 0, bx = 0, b8 = 0, b16 = 0, b8w = 0, hits = 0, both8 = 0;
-    double g16 = 0, g16pass = 0, g16recs = 0;     // groups of 16 records: group box = union of clipped boxes
-    double g8 = 0, g8pass = 0, g8recs = 0;
+    double visits = 0, recs = 0, cand = 0, hits = 0, runpass = 0;
+    double seg[4] = {0, 0, 0, 0}, segpass[4] = {0, 0, 0, 0}, segrecs[4] = {0, 0, 0, 0};   // list order 16, sorted 16, sorted 8, sorted 32
 };
 
 int main(int argc, char **argv)
@@ -139,28 +133,29 @@ int main(int argc, char **argv)
             for (uint32_t i = n.obj_begin; i < n.obj_begin + n.obj_count; i++) {
                 Pre &p = T.pre[i];
                 const LeafTri &lt = T.ft.leaf_tris[i];
-                SphereD s = clipped_triangle_sphere(lt, n);
-                for (int k = 0; k < 3; k++) p.xc[k] = s.c[k];
-                p.xr = s.r;
-                uint32_t w;
-                pack_sphere(&w, s, n, scale);
-                const uint32_t q[4] = {w & 255u, (w >> 8) & 255u, (w >> 16) & 255u, w >> 24};
-                for (int k = 0; k < 3; k++) p.sc[k] = ((double)q[k] - RT_SPH_ORG) / scale + n.lo[k];
-                p.sr = ((double)q[3] + 4e-3) / scale;
-                p.empty = !clipped_box(lt, n, p.blo, p.bhi);
-                if (p.empty) for (int k = 0; k < 3; k++) { p.blo[k] = n.lo[k]; p.bhi[k] = n.lo[k]; }
+                double blo[3], bhi[3];
+                p.empty = !clipped_box(lt, n, blo, bhi);
+                if (p.empty) for (int k = 0; k < 3; k++) { blo[k] = n.lo[k]; bhi[k] = n.lo[k]; }
                 for (int k = 0; k < 3; k++) {
-                    // clamp to the node's (grown) box, then to the grid 64 .. 191 (+-1), outward rounding
-                    double glo = (p.blo[k] - n.lo[k]) * scale + RT_SPH_ORG, ghi = (p.bhi[k] - n.lo[k]) * scale + RT_SPH_ORG;
-                    double flo = std::floor(glo - 1e-3), fhi = std::ceil(ghi + 1e-3);
+                    double glo = (blo[k] - n.lo[k]) * scale + RT_SPH_ORG, ghi = (bhi[k] - n.lo[k]) * scale + RT_SPH_ORG;
+                    double flo = std::floor(glo - 2e-3), fhi = std::ceil(ghi + 2e-3);
                     p.qlo[k] = (flo - RT_SPH_ORG) / scale + n.lo[k];
                     p.qhi[k] = (fhi - RT_SPH_ORG) / scale + n.lo[k];
-                    double s16 = scale * 256.0;
-                    double flo16 = std::floor((p.blo[k] - n.lo[k]) * s16 - 1e-3), fhi16 = std::ceil((p.bhi[k] - n.lo[k]) * s16 + 1e-3);
-                    p.q16lo[k] = flo16 / s16 + n.lo[k];
-                    p.q16hi[k] = fhi16 / s16 + n.lo[k];
                 }
             }
+        }
+        T.sorted.resize(T.ft.leaf_tris.size());
+        for (FlatNode &n : T.ft.nodes) {
+            const float scale = node_grid_scale(n);
+            std::vector<std::pair<uint32_t, uint32_t>> key(n.obj_count);
+            for (uint32_t i = 0; i < n.obj_count; i++) {
+                const Pre &p = T.pre[n.obj_begin + i];
+                uint32_t c[3];
+                for (int k = 0; k < 3; k++) c[k] = (uint32_t)std::min(255.0, std::max(0.0, ((p.qlo[k] + p.qhi[k]) / 2 - n.lo[k]) * scale + RT_SPH_ORG));
+                key[i] = {p.empty ? 0xFFFFFFFFu : morton3(c[0], c[1], c[2]), n.obj_begin + i};
+            }
+            std::sort(key.begin(), key.end());
+            for (uint32_t i = 0; i < n.obj_count; i++) T.sorted[n.obj_begin + i] = key[i].second;
         }
     }
     ai++;
@@ -205,39 +200,36 @@ int main(int argc, char **argv)
                     Stats &L = byLen[lb];
                     S.visits++; L.visits++;
                     double tempt = n1; uint32_t best = ~0u;
-                    for (uint32_t g0 = 0; g0 < n.obj_count; g0 += 8) {
-                        for (int gs = 8; gs <= 16; gs += 8) {
-                            if (g0 % gs) continue;
+                    {
+                        double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
+                        for (uint32_t i = 0; i < n.obj_count; i++) {
+                            const Pre &p = T.pre[n.obj_begin + i];
+                            if (p.empty) continue;
+                            for (int k = 0; k < 3; k++) { glo[k] = std::min(glo[k], p.qlo[k]); ghi[k] = std::max(ghi[k], p.qhi[k]); }
+                        }
+                        if (ray_box_window(e, d, glo, ghi, n0, n1)) { S.runpass++; L.runpass++; }
+                    }
+                    for (int variant = 0; variant < 4; variant++) {
+                        const uint32_t gs = variant == 2 ? 8 : (variant == 3 ? 32 : 16);
+                        for (uint32_t g0 = 0; g0 < n.obj_count; g0 += gs) {
                             double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
-                            uint32_t ge = std::min(g0 + gs, n.obj_count);
+                            const uint32_t ge = std::min(g0 + gs, n.obj_count);
                             bool any = false;
                             for (uint32_t i = g0; i < ge; i++) {
-                                const Pre &p = T.pre[n.obj_begin + i];
+                                const Pre &p = T.pre[variant ? T.sorted[n.obj_begin + i] : n.obj_begin + i];
                                 if (p.empty) continue;
                                 any = true;
                                 for (int k = 0; k < 3; k++) { glo[k] = std::min(glo[k], p.qlo[k]); ghi[k] = std::max(ghi[k], p.qhi[k]); }
                             }
-                            bool pass = any && ray_box_window(e, d, glo, ghi, n0, n1);
-                            if (gs == 16) { S.g16++; L.g16++; if (pass) { S.g16pass++; L.g16pass++; S.g16recs += ge - g0; L.g16recs += ge - g0; } }
-                            else { S.g8++; L.g8++; if (pass) { S.g8pass++; L.g8pass++; S.g8recs += ge - g0; L.g8recs += ge - g0; } }
+                            const bool pass = any && ray_box_window(e, d, glo, ghi, n0, n1);
+                            S.seg[variant]++; L.seg[variant]++;
+                            if (pass) { S.segpass[variant]++; L.segpass[variant]++; S.segrecs[variant] += ge - g0; L.segrecs[variant] += ge - g0; }
                         }
                     }
                     for (uint32_t i = n.obj_begin; i < n.obj_begin + n.obj_count; i++) {
                         const Pre &p = T.pre[i];
                         S.recs++; L.recs++;
-                        const bool a = line_sphere(e, d, p.sc, p.sr);
-                        const bool b = line_sphere(e, d, p.xc, p.xr);
-                        const bool c = !p.empty && ray_box_window(e, d, p.blo, p.bhi, -1e300, 1e300);
-                        const bool c8 = !p.empty && ray_box_window(e, d, p.qlo, p.qhi, -1e300, 1e300);
-                        const bool c16 = !p.empty && ray_box_window(e, d, p.q16lo, p.q16hi, -1e300, 1e300);
-                        const bool c8w = !p.empty && ray_box_window(e, d, p.qlo, p.qhi, n0, n1);
-                        if (a) { S.s8++; L.s8++; }
-                        if (b) { S.sx++; L.sx++; }
-                        if (c) { S.bx++; L.bx++; }
-                        if (c8) { S.b8++; L.b8++; }
-                        if (c16) { S.b16++; L.b16++; }
-                        if (c8w) { S.b8w++; L.b8w++; }
-                        if (a && c8w) { S.both8++; L.both8++; }
+                        if (!p.empty && ray_box_window(e, d, p.qlo, p.qhi, n0, n1)) { S.cand++; L.cand++; }
                         double tt;
                         if (tri_hit(ft.leaf_tris[i], e, d, n0, tempt, tt)) { tempt = tt; best = i; S.hits++; L.hits++; }
                     }
@@ -284,16 +276,17 @@ int main(int argc, char **argv)
     printf("rays %.0f  inner/ray %.2f  leaf/ray %.2f\n", nrays, ninner / nrays, nleaf / nrays);
     auto row = [&](const char *name, int k, const Stats &S) {
         if (!S.visits) return;
-        printf("%s %2d: visits/ray %6.3f recs/ray %7.2f | per ray: s8 %6.2f sx %6.2f bx %6.2f b8 %6.2f b16 %6.2f b8w %6.2f s8&b8w %6.2f hit %5.2f | g16: groups/ray %6.2f pass %5.1f%% recs-after/ray %7.2f | g8: groups/ray %6.2f pass %5.1f%% recs-after/ray %7.2f\n",
-               name, k, S.visits / nrays, S.recs / nrays, S.s8 / nrays, S.sx / nrays, S.bx / nrays, S.b8 / nrays, S.b16 / nrays, S.b8w / nrays, S.both8 / nrays, S.hits / nrays,
-               S.g16 / nrays, 100 * S.g16pass / std::max(S.g16, 1.0), S.g16recs / nrays, S.g8 / nrays, 100 * S.g8pass / std::max(S.g8, 1.0), S.g8recs / nrays);
+        printf("%s %2d: visits/ray %6.3f run-box pass %5.1f%% recs/ray %7.2f cand %6.2f hit %5.2f |", name, k, S.visits / nrays, 100 * S.runpass / S.visits, S.recs / nrays, S.cand / nrays, S.hits / nrays);
+        const char *vn[4] = {"list16", "sort16", "sort8", "sort32"};
+        for (int v = 0; v < 4; v++) printf(" %s: segs %6.2f pass %5.1f%% recs-after %6.2f |", vn[v], S.seg[v] / nrays, 100 * S.segpass[v] / std::max(S.seg[v], 1.0), S.segrecs[v] / nrays);
+        printf("\n");
     };
     Stats tot;
     for (int k = 0; k <= MAXD; k++) {
         row("depth", k, byDepth[k]);
         const Stats &S = byDepth[k];
-        tot.visits += S.visits; tot.recs += S.recs; tot.s8 += S.s8; tot.sx += S.sx; tot.bx += S.bx; tot.b8 += S.b8; tot.b16 += S.b16; tot.b8w += S.b8w; tot.both8 += S.both8; tot.hits += S.hits;
-        tot.g16 += S.g16; tot.g16pass += S.g16pass; tot.g16recs += S.g16recs; tot.g8 += S.g8; tot.g8pass += S.g8pass; tot.g8recs += S.g8recs;
+        tot.visits += S.visits; tot.recs += S.recs; tot.cand += S.cand; tot.hits += S.hits; tot.runpass += S.runpass;
+        for (int v = 0; v < 4; v++) { tot.seg[v] += S.seg[v]; tot.segpass[v] += S.segpass[v]; tot.segrecs[v] += S.segrecs[v]; }
     }
     row("total", 0, tot);
     for (int k = 0; k < 12; k++) row("len2^", k, byLen[k]);
