@@ -3,6 +3,7 @@
 // every trace / render entry point runs the gfx950 kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -402,26 +403,60 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     // number -- runs lie in node order, so these places are distinct and in order (a run of c records has at
     // most c / RT_SEG_RECS + 1 segments).  Spare boxes behind the last record: the kernels read the boxes of
     // a whole segment from any record on.
+    // The records of a run are put in the Morton order of their boxes' centres first, so that a segment's
+    // records lie together and its box is small.  A node's list holds its primitives by increasing index
+    // (they are inserted in index order, and a node that splits hands its list on in order,
+    // octree.cpp:61-99), so "the later of two equal hits" (octree.cpp:31) is the one with the larger index
+    // and the kernels can settle ties by index whatever the order of the records.  The run of a mesh whose
+    // whole octree is one leaf keeps its order: the object sweep walks it record by record.
     std::vector<uint32_t> leaf_box((leaf_tris.size() + RT_SPH_SPARE) * 2);
     std::vector<uint32_t> seg_box((leaf_tris.size() / RT_SEG_RECS + nodes.size() + 2) * 2);
     std::vector<uint32_t> run_box(nodes.size() * 2 + 2);          // per node: the union of its run's boxes
     for (size_t i = 0; i < leaf_box.size() / 2; i++) store_whole_node_box(&leaf_box[2 * i]);
     for (size_t i = 0; i < seg_box.size() / 2; i++) store_whole_node_box(&seg_box[2 * i]);
+    std::vector<bool> keep_order(nodes.size(), false);
+    for (uint64_t mi = 0; mi < d->nmeshes; mi++)
+        if (nodes[mesh_root[mi]].child_base == 0) keep_order[mesh_root[mi]] = true;
+    struct RecBox { uint32_t w[2]; int lo[3], hi[3]; uint32_t key, id, src; };
+    std::vector<RecBox> rb;
+    std::vector<LeafTri> moved;
     for (size_t ni = 0; ni < nodes.size(); ni++) {
         FlatNode &n = nodes[ni];
         const float scale = node_grid_scale(n);
         uint32_t bits;
         std::memcpy(&bits, &scale, 4);
         n.pad = bits | (n.pad & 1u);                  // grid scale, voxel flag in the lowest bit
+        rb.resize(n.obj_count);
+        bool sortable = !keep_order[ni];
+        for (uint32_t j = 0; j < n.obj_count; j++) {
+            const LeafTri &t = leaf_tris[n.obj_begin + j];
+            RecBox &r = rb[j];
+            const BoxD b = (t.id & LEAF_VOXEL) ? clipped_voxel_box(t, n) : clipped_triangle_box(t, n);
+            pack_box(r.w, b, n, scale, r.lo, r.hi);
+            r.id = t.id; r.src = j;
+            r.key = 0xFFFFFFFFu;                          // nothing of the primitive inside the node: to the end
+            if (r.lo[0] <= r.hi[0]) {
+                r.key = 0;
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t c2 = (uint32_t)(r.lo[k] + r.hi[k]);       // twice the centre: 9 bits
+                    for (int bit = 0; bit < 9; bit++) r.key |= ((c2 >> bit) & 1u) << (3 * bit + k);
+                }
+            }
+            if (j && !(rb[j - 1].id < r.id)) sortable = false;
+        }
+        if (sortable && n.obj_count > 1) {
+            std::sort(rb.begin(), rb.end(), [](const RecBox &a, const RecBox &b) { return a.key != b.key ? a.key < b.key : a.id < b.id; });
+            moved.assign(leaf_tris.begin() + n.obj_begin, leaf_tris.begin() + n.obj_begin + n.obj_count);
+            for (uint32_t j = 0; j < n.obj_count; j++) leaf_tris[n.obj_begin + j] = moved[rb[j].src];
+        }
         const size_t seg0 = (size_t)(n.obj_begin / RT_SEG_RECS) + ni;
         int rlo[3] = {256, 256, 256}, rhi[3] = {-1, -1, -1};
         for (uint32_t j = 0; j < n.obj_count; j += RT_SEG_RECS) {
             int ulo[3] = {256, 256, 256}, uhi[3] = {-1, -1, -1};
-            for (uint32_t i = n.obj_begin + j; i < n.obj_begin + n.obj_count && i < n.obj_begin + j + RT_SEG_RECS; i++) {
-                int lo[3], hi[3];
-                const BoxD b = (leaf_tris[i].id & LEAF_VOXEL) ? clipped_voxel_box(leaf_tris[i], n) : clipped_triangle_box(leaf_tris[i], n);
-                pack_box(&leaf_box[(size_t)i * 2], b, n, scale, lo, hi);
-                for (int k = 0; k < 3; k++) { if (lo[k] < ulo[k]) ulo[k] = lo[k]; if (hi[k] > uhi[k]) uhi[k] = hi[k]; }
+            for (uint32_t i = j; i < n.obj_count && i < j + RT_SEG_RECS; i++) {
+                leaf_box[((size_t)n.obj_begin + i) * 2] = rb[i].w[0];
+                leaf_box[((size_t)n.obj_begin + i) * 2 + 1] = rb[i].w[1];
+                for (int k = 0; k < 3; k++) { if (rb[i].lo[k] < ulo[k]) ulo[k] = rb[i].lo[k]; if (rb[i].hi[k] > uhi[k]) uhi[k] = rb[i].hi[k]; }
             }
             store_grid_box(&seg_box[(seg0 + j / RT_SEG_RECS) * 2], ulo, uhi);
             for (int k = 0; k < 3; k++) { if (ulo[k] < rlo[k]) rlo[k] = ulo[k]; if (uhi[k] > rhi[k]) rhi[k] = uhi[k]; }

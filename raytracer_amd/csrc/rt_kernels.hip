@@ -554,7 +554,7 @@ struct CoopLds {                 // per wave
     union {
         struct {
             unsigned long long okey[64]; // per owner lane, per pass: smallest hit distance as an ordered integer
-            unsigned long long owin[64]; //   (list position + 1) << 32 | primitive id of the last candidate that reached it
+            uint32_t owin[64];           //   primitive id << 1 | sign of a zero distance, the largest among the candidates that reached it
         };
         uint64_t raw[64];        // raw table of a round (entries as in seg); no fp64 pass runs while it is in use
     };
@@ -617,7 +617,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             const uint32_t left = produced - tested, n = left < 64u ? left : 64u;
             const bool act = lane < n;
             const uint32_t slot = (tested + lane) & (RT_CAND_CAP - 1u);
-            L.okey[lane] = ~0ull; L.owin[lane] = 0ull;
+            L.okey[lane] = ~0ull; L.owin[lane] = 0u;
             const uint32_t rec = act ? L.crec[slot] : 0u;
             const int o = act ? (int)L.cown[slot] : (int)lane;
             TriReg R = {};
@@ -652,9 +652,11 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             // LDS operations of one wave are carried out in the order they are issued, so each stage
             // below sees the stage before it; the wave barriers only keep the compiler from mixing them
             // -0.0 and +0.0 are one distance to `t <= tempt` (octree.cpp:31), so they share a key; the
-            // winner's own sign of zero travels in the free top bit of the id word
+            // winner's own sign of zero travels in the lowest bit of the id word.  Of equal distances the
+            // primitive that comes later in the node's list wins, and that is the one with the larger
+            // index (the list is in index order; the records of a run are not)
             const unsigned long long key = ordered_key(tt + 0.0);
-            if (tt == 0.0 && __builtin_signbit(tt)) id |= 0x80000000u;
+            const uint32_t idw = (id << 1) | ((tt == 0.0 && __builtin_signbit(tt)) ? 1u : 0u);
 #if RT_STEP_STATS == 8
             if (__builtin_amdgcn_readfirstlane((int)(key != 0ull)) >= 0 && lane == 0) c.prim += (uint32_t)((clock64() - tp0) >> 4);
 #endif
@@ -662,15 +664,15 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             if (hit) atomicMin(&L.okey[o], key);
             __builtin_amdgcn_wave_barrier();
             const bool best = hit && L.okey[o] == key;
-            if (best) atomicMax(&L.owin[o], ((unsigned long long)(lane + 1u) << 32) | id);      // a pass's candidates are in list order lane by lane
+            if (best) atomicMax(&L.owin[o], idw);
             __builtin_amdgcn_wave_barrier();
             if (owner) {
                 const unsigned long long k = L.okey[lane];
                 if (k != ~0ull) {
                     const double t = ordered_value(k);
-                    if (t <= T.tempt) {                                                       // octree.cpp:30-33
-                        const uint32_t w = (uint32_t)L.owin[lane];
-                        T.tempt = (w & 0x80000000u) ? -0.0 : t; T.bprim = w & 0x7FFFFFFFu;
+                    const uint32_t w = L.owin[lane];
+                    if (t < T.tempt || (t == T.tempt && (T.bprim == RT_MISS || (w >> 1) > T.bprim))) {   // octree.cpp:30-33
+                        T.tempt = (w & 1u) ? -0.0 : t; T.bprim = w >> 1;
                     }
                 }
             }
