@@ -34,12 +34,8 @@ VALU_FP64_PEAK = 39.3e12       # 256 CU x 4 SIMD x 16 fp64 lanes/clk x 2.4 GHz (
                                # the path is built without contraction, so an operation is one flop)
 RAY_RECORD_BYTES = 88.0        # a pending bounce ray: 11 eight-byte fields
 SHADOW_RECORD_BYTES = 84.0     # a pending shadow ray: 10 eight-byte fields and the pixel index
-# a "launch" of the closest-hit stage is one call of the library's launcher: the engine over a chunk
-# of a ray stack, or -- for rays expected to stay outside the octrees -- the object-sweep kernel
-# followed by the engine over the rays that reached an octree after all
-TRACE_KERNELS = ("closest-hit stage: rt::k_trace / rt::k_trace_shadow (octree engine), "
-                 "rt::k_sweep / rt::k_sweep_shadow + rt::k_trace_retry / rt::k_trace_shadow_retry (rays outside the octrees)")
 SHADE_READ_BYTES = 40.0        # what shading reads of every ray: meta word, hit id, throughput
+BOX_TEST_OPS = 23.0            # one single-precision box pre-test: 6 conversions, 6 multiply-adds, 10 minima / maxima, 1 compare
 
 
 def shade_bytes(flow):
@@ -48,13 +44,6 @@ def shade_bytes(flow):
     out): the fields every ray is read for, and one record written per follow-up ray."""
     return (SHADE_READ_BYTES * flow["shaded_in"] + RAY_RECORD_BYTES * (flow["bounce_class0"] + flow["bounce_class1"])
             + SHADOW_RECORD_BYTES * (flow["shadow_class0"] + flow["shadow_class1"]))
-
-
-def algorithmic_lane_ops(cnt):
-    """fp64 lane-operations of the same work: 26 per slab test (node box + 8 children at an
-    inner node, node box at a leaf), 50 per triangle test."""
-    rays, inner, leaf, prim = (float(x) for x in cnt)
-    return 26.0 * 9.0 * inner + 26.0 * leaf + 50.0 * prim
 
 
 def cpu_baseline(desc, cam, W, H, n, m, seed, budget_s=20.0):
@@ -246,6 +235,7 @@ def main():
     cnt.zero_()
     sc.set_profiling(True)
     sc.get_profile(reset=True)
+    sc.get_kernel_stats(reset=True)
     sc.get_ray_flow(reset=True)
     fence()
     t0 = time.perf_counter()
@@ -255,6 +245,7 @@ def main():
     dt = time.perf_counter() - t0
     sc.check()
     prof = sc.get_profile()
+    kst = sc.get_kernel_stats()
     flow = sc.get_ray_flow()
     sc.set_profiling(False)
 
@@ -270,22 +261,20 @@ def main():
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
     total = total.cpu().numpy().astype(np.float64)
-    mine = cnt.cpu().numpy().astype(np.float64)
 
     if rank == 0:
         steps = max(a.steps, 1)
         rays_per_step = total[0] / steps
         paths_per_step = float(W) * H * n * m
-        # Dominant kernel: the closest-hit kernel, timed with HIP events around every launch on the
-        # stream it runs on.  Its scene data stays in the caches, so what binds it is fp64 vector
-        # arithmetic, not HBM: the headline roofline prices the work it did (slab tests and
-        # primitive tests by the device's own counters) against the fp64 vector peak.  HBM traffic
-        # comes from counter passes of the same command (profiles/, replayed here: a --pmc pass
-        # cannot run inside this process) and is reported as a secondary entry.
-        launches = max(prof["trace_launches"], 1.0)
-        avg_ms = prof["trace_ms"] / launches
-        ops_per_launch = algorithmic_lane_ops(mine) / launches
-        achieved_ops = ops_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        # Dominant kernel: rt::k_trace, the octree engine over bounce rays, timed with HIP events around
+        # every launch on the stream it runs on; the other stages of the closest-hit search are listed
+        # beside it, each with its own device counters.  The scene data stays in the caches, so what binds
+        # these kernels is vector arithmetic, not HBM.  `frac` prices the work by the per-unit figures
+        # of the reference's walk (slab tests and primitive tests it makes: N_n, N_l, N_p counted on the
+        # device) against the fp64 vector peak; the kernels' box pre-tests skip most of those primitive
+        # tests, so `executed_frac` prices what was actually executed for the same rays.  HBM traffic
+        # comes from counter passes of the same command (profiles/, replayed here: a --pmc pass cannot
+        # run inside this process).
         pmc = {}
         pfile = os.path.join(ROOT, "profiles", "pmc_" + a.workload + ".json")
         # the counter passes were made on the default frame of the workload (per GPU: weak scaling keeps it);
@@ -295,7 +284,7 @@ def main():
                 pmc = json.load(open(pfile))
             except Exception:
                 pmc = {}
-        ptrace, pshade = pmc.get("trace", {}), pmc.get("shade", {})
+        src = f"replayed from profiles/pmc_{a.workload}.json (rocprofv3 --pmc passes of this command, {pmc.get('collected', 'n/a')})" if pmc else None
 
         def per_launch(fig, launches_per_step):
             """HBM bytes per launch: the profiled step's total for the kernel (the same frame) over this run's launches per step."""
@@ -303,12 +292,38 @@ def main():
                 return None
             return (fig["fetch_bytes_total_corrected"] + fig["write_bytes_total"]) / max(launches_per_step, 1.0)
 
-        traffic = per_launch(ptrace, prof["trace_launches"] / steps)
-        src = f"replayed from profiles/pmc_{a.workload}.json (rocprofv3 --pmc passes of this command, {pmc.get('collected', 'n/a')})" if pmc else None
+        def trace_entry(name, st, fig):
+            launches = max(st["launches"], 1.0)
+            avg_ms = st["ms"] / launches
+            alg = 26.0 * 9.0 * st["inner"] + 26.0 * st["leaf"] + 50.0 * st["prim"]
+            exe = 26.0 * 9.0 * st["inner"] + 26.0 * st["leaf"] + 50.0 * st["fp64_tests"] + BOX_TEST_OPS * st["box_tests"]
+            rate = lambda ops: ops / (st["ms"] * 1e-3) if st["ms"] > 0 else 0.0
+            rays = max(st["rays"], 1.0)
+            issue, lanes = fig.get("valu_issue_share"), fig.get("active_lanes_per_valu_inst")
+            return {"kernel": name, "bound": "valu-fp64",
+                    "achieved": rate(alg) / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "TFLOP/s", "frac": rate(alg) / VALU_FP64_PEAK,
+                    "traffic": per_launch(fig, st["launches"] / steps), "traffic_source": src if fig else None,
+                    "launches": st["launches"], "avg_launch_ms": avg_ms, "algorithmic_ops_per_launch": alg / launches,
+                    "ops_model": "26 per slab test (9 at an inner node, 1 at a leaf) + 50 per primitive the reference's walk tests (N_p), counted on the device; "
+                                 "the box pre-tests cull most of those tests, which are priced all the same, so this is a rate of useful work and is not bounded by 1",
+                    "executed_ops_per_launch": exe / launches, "executed_achieved": rate(exe) / 1e12, "executed_frac": rate(exe) / VALU_FP64_PEAK,
+                    "executed_model": f"the same slab tests + 50 per fp64 primitive test made + {BOX_TEST_OPS:.0f} per single-precision box test made",
+                    "rays": st["rays"], "inner_visits_per_ray": st["inner"] / rays, "leaf_visits_per_ray": st["leaf"] / rays,
+                    "covered_prims_per_ray": st["prim"] / rays, "executed_fp64_tests_per_ray": st["fp64_tests"] / rays,
+                    "executed_box_tests_per_ray": st["box_tests"] / rays,
+                    "hw_valu_issue_share": issue, "hw_active_lanes_per_valu_inst": lanes,
+                    "hw_valu_lane_util": issue * lanes / 64.0 if issue is not None and lanes is not None else None,
+                    "share_of_step_time": st["ms"] * 1e-3 / dt}
+
+        pm_names = ("k_trace", "k_trace_shadow", "k_sweep", "k_sweep_shadow")
+        full = ("rt::k_trace (octree engine, bounce rays)", "rt::k_trace_shadow (octree engine, shadow rays)",
+                "rt::k_sweep + rt::k_trace_retry (bounce rays outside the octrees)", "rt::k_sweep_shadow + rt::k_trace_shadow_retry (shadow rays outside the octrees)")
+        entries = [trace_entry(full[i], kst[hip.HipScene.KERNEL_STAGES[i]], pmc.get(pm_names[i], {})) for i in range(4)]
         shade_launches = max(prof["shade_launches"], 1.0)
         shade_avg_ms = prof["shade_ms"] / shade_launches
         shade_b = shade_bytes(flow) / shade_launches
         shade_gbs = shade_b / (shade_avg_ms * 1e-3) / 1e9 if shade_avg_ms > 0 else 0.0
+        pshade = pmc.get("shade", {})
         out = {
             "metric": "Mrays/s (whole job; spp/s and roofline fractions alongside)",
             "value": rays_per_step * steps / dt / 1e6,
@@ -334,13 +349,8 @@ def main():
             "rays_per_path": rays_per_step / paths_per_step,
             "upload_s": upload_s,
             "workspace_gb": sc.workspace_bytes() / 1e9,
-            "roofline": {"kernel": TRACE_KERNELS, "bound": "valu-fp64",
-                         "achieved": achieved_ops / 1e12, "peak": VALU_FP64_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved_ops / VALU_FP64_PEAK, "traffic": traffic, "traffic_source": src,
-                         "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_ops_per_launch": ops_per_launch,
-                         "ops_model": "26 per slab test (9 at an inner node, 1 at a leaf) + 50 per primitive test, counted on the device",
-                         "valu_issue_share": ptrace.get("valu_issue_share"), "active_lanes_per_valu_inst": ptrace.get("active_lanes_per_valu_inst"),
-                         "share_of_step_time": prof["trace_ms"] * 1e-3 / dt},
+            "roofline": entries[0],
+            "roofline_other_trace_kernels": entries[1:],
             "roofline_shade": {"kernel": "rt::k_shade (shading + ray append)", "bound": "hbm",
                                "achieved": shade_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": shade_gbs / HBM_PEAK_GBS,
                                "traffic": per_launch(pshade, prof["shade_launches"] / steps), "traffic_source": src if pshade else None,
@@ -349,14 +359,18 @@ def main():
             "stage_ms_per_step": {"trace": prof["trace_ms"] / steps, "shade": prof["shade_ms"] / steps,
                                   "rounds": prof["rounds"] / steps},
         }
-        if traffic and avg_ms > 0:
-            gbs = traffic / (avg_ms * 1e-3) / 1e9
-            out["roofline_hbm"] = {"kernel": TRACE_KERNELS, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+        tr = entries[0]["traffic"]
+        if tr and entries[0]["avg_launch_ms"] > 0:
+            gbs = tr / (entries[0]["avg_launch_ms"] * 1e-3) / 1e9
+            out["roofline_hbm"] = {"kernel": entries[0]["kernel"], "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
                                    "note": "measured traffic of the profiled run over this run's launch time: the scene is cache resident, HBM does not bind"}
-        for key in ("roofline", "roofline_shade", "roofline_hbm"):
+        for key in ("roofline_shade", "roofline_hbm"):
             if key in out and not (0.0 <= out[key]["frac"] <= 1.0):
                 raise SystemExit(f"bench.py: {key}.frac = {out[key]['frac']:.3f} is not a fraction of a peak -- the model behind it is wrong")
+        for e in entries:
+            if not (0.0 <= e["executed_frac"] <= 1.0):
+                raise SystemExit(f"bench.py: executed_frac = {e['executed_frac']:.3f} of {e['kernel']} is not a fraction of a peak -- the count behind it is wrong")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(desc, cam, W, H, n, m, seed, a.cpu_budget)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -257,6 +257,17 @@ int rt_scene_check(rt_scene *scene, void *stream);
  * the totals after reading. */
 int rt_scene_set_profiling(rt_scene *scene, int enable);
 int rt_scene_get_profile(rt_scene *scene, double out[6], int reset);
+/* Per stage of the closest-hit search, while profiling is enabled (no counterpart in the reference).
+ * Stages: 0 = rt::k_trace (bounce rays through the octree engine), 1 = rt::k_trace_shadow (shadow rays
+ * through the engine), 2 = rt::k_sweep followed by rt::k_trace_retry (bounce rays expected to stay outside
+ * the octrees), 3 = rt::k_sweep_shadow followed by rt::k_trace_shadow_retry.  out = RT_KSTAT_STAGES rows of
+ * RT_KSTAT_ROW doubles: {launches, total ms, rays, inner-node visits, leaf visits, primitives covered (the
+ * four work counters of rt_render), single-precision box tests executed, double-precision primitive tests
+ * executed, 0, 0}.  "Covered" counts every primitive of every run the reference's walk opens; "executed"
+ * counts the tests that were made for them (boxes cull the rest).  Synchronises the device. */
+#define RT_KSTAT_STAGES 4
+#define RT_KSTAT_ROW 10
+int rt_scene_get_kernel_stats(rt_scene *scene, double *out, int reset);
 /* Rays that went through the path-tracing pipeline since the last reset, counted by the host
  * driver (always, profiling enabled or not): out = {first rays generated, rays traced and handed
  * to shading, bounce rays appended that end inside object phases, bounce rays appended that reach

@@ -69,6 +69,8 @@ struct rt_scene {
     int profiling = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof[6] = {0, 0, 0, 0, 0, 0}; // trace launches, trace ms, shade launches, shade ms, generate launches, rounds
+    double kprof[RT_KSTAT_STAGES][2] = {};   // per stage of the closest-hit search: launches, ms
+    uint64_t *d_kstats = nullptr;        // RT_KSTAT_STAGES x RT_KSTAT_WORDS device counters (profiling)
     double flow[6] = {0, 0, 0, 0, 0, 0}; // first rays generated, rays traced and shaded, bounce rays appended (class 0, 1), shadow rays appended (class 0, 1)
 };
 
@@ -239,6 +241,7 @@ int rt_scene_destroy(rt_scene *s)
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->ws_mem) (void)hipFree(s->ws_mem);
     if (s->d_ctrl) (void)hipFree(s->d_ctrl);
+    if (s->d_kstats) (void)hipFree(s->d_kstats);
     if (s->h_ctrl) (void)hipHostFree(s->h_ctrl);
     for (int k = 0; k < 5; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     delete s;
@@ -473,6 +476,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     up(objs, &p_obj); up(mats, &p_mat); up(lights, &p_light); up(nodes, &p_nodes); up(leaf_tris, &p_idx); up(tri_normals, &p_tris); up(leaf_box, &p_sph); up(seg_box, &p_seg); up(run_box, &p_run);
     up(perlin_p, &p_pp); up(perlin_g, &p_pg);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctrl, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_kstats, RT_KSTAT_STAGES * RT_KSTAT_WORDS * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemset(s->d_kstats, 0, RT_KSTAT_STAGES * RT_KSTAT_WORDS * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_ctrl, 64, hipHostMallocDefault);
     if (e != hipSuccess) { rt_scene_destroy(s); return fail_hip("scene upload", e); }
     s->dev.objects = (const DevObject *)p_obj;
@@ -681,6 +686,7 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
     const uint64_t max_push = (uint64_t)s->max_push, max_shadow = (uint64_t)s->max_shadow, cap = ws.cap, target = ws.target;
     uint32_t *const d_ctrl = ws.d_ctrl;
     s->failed = 0;              // a failure of an earlier call has been reported by rt_scene_check or by that call's own status
+    A.kstats = s->profiling ? s->d_kstats : nullptr;
     uint64_t count[2][2] = {{0, 0}, {0, 0}};      // radiance rays pending, [class][side]
     uint64_t scount[2] = {0, 0};                  // shadow rays pending, [class]
     int cur[2] = {0, 0};                          // side that is the class's source
@@ -703,6 +709,8 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
             HIP_TRY(hipEventSynchronize(s->ev[4]));
             HIP_TRY(hipEventElapsedTime(&a, s->ev[3], s->ev[4]));
             s->prof[0] += 1; s->prof[1] += a;
+            const int stage = cls ? RT_KSTAT_ENGINE_SHADOW : RT_KSTAT_SWEEP_SHADOW;
+            s->kprof[stage][0] += 1; s->kprof[stage][1] += a;
         }
         scount[cls] = 0;
         return 0;
@@ -760,6 +768,8 @@ static int wavefront_loop(rt_scene *s, const WaveSpace &ws, WaveArgs &A, uint64_
             HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
             HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
             s->prof[0] += 1; s->prof[1] += a; s->prof[2] += 1; s->prof[3] += b;
+            const int stage = X ? RT_KSTAT_ENGINE : RT_KSTAT_SWEEP;
+            s->kprof[stage][0] += 1; s->kprof[stage][1] += a;
         }
         s->prof[5] += 1;
         s->flow[1] += (double)c;
@@ -927,6 +937,24 @@ int rt_scene_get_profile(rt_scene *s, double out[6], int reset)
     if (!s || !out) return fail("rt_scene_get_profile: null argument");
     for (int k = 0; k < 6; k++) out[k] = s->prof[k];
     if (reset) for (int k = 0; k < 6; k++) s->prof[k] = 0;
+    return 0;
+}
+
+int rt_scene_get_kernel_stats(rt_scene *s, double *out, int reset)
+{
+    if (!s || !out) return fail("rt_scene_get_kernel_stats: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    uint64_t h[RT_KSTAT_STAGES * RT_KSTAT_WORDS];
+    HIP_TRY(hipMemcpy(h, s->d_kstats, sizeof h, hipMemcpyDeviceToHost));
+    for (int k = 0; k < RT_KSTAT_STAGES; k++) {
+        double *o = out + k * (2 + RT_KSTAT_WORDS);
+        o[0] = s->kprof[k][0]; o[1] = s->kprof[k][1];
+        for (int j = 0; j < RT_KSTAT_WORDS; j++) o[2 + j] = (double)h[k * RT_KSTAT_WORDS + j];
+    }
+    if (reset) {
+        HIP_TRY(hipMemset(s->d_kstats, 0, sizeof h));
+        for (int k = 0; k < RT_KSTAT_STAGES; k++) s->kprof[k][0] = s->kprof[k][1] = 0;
+    }
     return 0;
 }
 

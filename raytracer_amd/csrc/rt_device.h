@@ -15,7 +15,10 @@ namespace rt {
 #define RT_SPH_EDGE 127u
 #define RT_SPH_ORG 64u
 #define RT_SPH_SPARE 64          // spare boxes after the last record: a chunk of 64 is read from any record on without clamping
-#define RT_SEG_RECS 16           // records per segment of a run: every segment has a box of its own (the union of its records')
+#ifndef RT_SEG_RECS
+#define RT_SEG_RECS 16
+#endif
+// RT_SEG_RECS = records per segment of a run: every segment has a box of its own (the union of its records')
 
 // One Group child as the kernels see it.  The object phase of the closest-hit engine reads
 // this table at wave-uniform addresses (scalar loads); a record carries everything that phase
@@ -115,6 +118,12 @@ struct RayDest {
 #define RT_STATIC_SCRATCH_BYTES ((64u << 20) + 256u)
 #define RT_NOALLOC_MAX_RAYS (1u << 20)
 
+// Counters per stage of the closest-hit search, kept while profiling is on: the four work counters, then
+// box tests and fp64 primitive tests executed, two spare words.  A sweep stage includes the engine's
+// launch over its retry list.
+enum { RT_KSTAT_ENGINE = 0, RT_KSTAT_ENGINE_SHADOW = 1, RT_KSTAT_SWEEP = 2, RT_KSTAT_SWEEP_SHADOW = 3, RT_KSTAT_WORDS = 8 };
+static_assert(RT_KSTAT_STAGES == 4 && RT_KSTAT_ROW == 2 + RT_KSTAT_WORDS, "rt_scene_get_kernel_stats rows");
+
 struct WaveArgs {
     rt_camera cam;
     int32_t  width, height;
@@ -130,6 +139,7 @@ struct WaveArgs {
     int32_t  pad;
     double   *out;             // camera: radiance_sum [H][W][3] ; batch: out [n][3]   (atomic +=)
     uint64_t *counters;        // nullable: {rays, inner visits, leaf visits, primitive tests}
+    uint64_t *kstats;          // nullable (profiling): RT_KSTAT_STAGES blocks of RT_KSTAT_WORDS counters, one per stage of the closest-hit search
 };
 
 } // namespace rt

@@ -125,7 +125,9 @@ __device__ __forceinline__ bool hit_box(V3 lo, V3 hi, V3 e, V3 d, double t0, dou
     return r0 <= r1;
 }
 
-struct Counters { uint32_t rays, inner, leaf, prim; };
+// rays traced, inner-node and leaf visits, primitives covered (what the reference's walk tests); then what
+// was executed for them: single-precision box tests and double-precision primitive tests
+struct Counters { uint32_t rays, inner, leaf, prim, box, fp64; };
 
 // One 80-byte triangle record in registers.
 struct TriReg { double v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z; uint32_t id; };
@@ -495,6 +497,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         rb.ix = fi.x; rb.iy = fi.y; rb.iz = fi.z;
         rb.cx = -(gx * fi.x); rb.cy = -(gy * fi.y); rb.cz = -(gz * fi.z);
         rb.tend = (float)(n1 - n0) * dlen * sc + RT_BOX_SLACK;
+        c.box++;
         if (!box_pass(run_box.x, run_box.y, rb)) {
             // the ray passes everything in this run at a distance: the run is covered without a look at
             // its records (mode stays TM_POP: nothing was hit here)
@@ -590,6 +593,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
     const uint32_t lane = threadIdx.x & 63u, wave0 = threadIdx.x & ~63u;
     const uint32_t sub = (lane % LANES_PER_SEG) * RT_LANE_RECS, sseg = lane / LANES_PER_SEG;     // the lane's place in a chunk
     uint32_t produced = 0, tested = 0;                 // candidates appended / tested so far (wave-uniform)
+    uint32_t nbox = 0;                                 // box tests made for segments and records (wave-uniform)
     const bool owner = mode == TM_TRI;
     uint32_t kcur = T.k;                               // first record of the owner's run that is not scheduled yet
     const uint32_t segbase = T.k / RT_SEG + T.cur;     // where the boxes of the owner's segments start (DevScene::seg_box)
@@ -767,8 +771,10 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                 for (int r = 0; r < RT_LANE_RECS; r++) {
                     const bool in_seg = sub + (uint32_t)r < cnt, near = box_pass(w[r][0], w[r][1], rf);
                     p[r] = in_seg & near;
-                    m[r] = ballot64(in_seg) & ballot64(near);                     // two compare masks and a scalar AND
+                    const unsigned long long im = ballot64(in_seg);
+                    m[r] = im & ballot64(near);                                   // two compare masks and a scalar AND
                     np += (uint32_t)__popcll(m[r]);
+                    nbox += (uint32_t)__popcll(im);
                 }
 #if RT_STEP_STATS == 7
                 if (lane == 0) c.inner += 1;                    // chunks
@@ -853,6 +859,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
             const unsigned long long pm = ballot64(pass);
             if (pass) L.seg[count_below(pm, work_n)] = rawe;
             work_n += (uint32_t)__popcll(pm);
+            nbox += total;
 #if RT_STEP_STATS == 10
             if (lane == 0) { c.rays += 1; c.inner += total; c.leaf += (uint32_t)__popcll(pm); }      // rounds, segments listed, segments that pass
 #endif
@@ -876,6 +883,9 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
     test_all();
     RT_TICK8(rays)
     RT_TICK9(prim)
+#if !defined(RT_STEP_STATS)
+    if (lane == 0) { c.box += nbox; c.fp64 += tested; }
+#endif
     if (owner) {
 #if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9 && RT_STEP_STATS != 10
         c.prim += T.kend - T.k;
@@ -1062,7 +1072,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                         hb = T.fast ? hit_box_fast(lo, hi, T.e, T.d, T.r, T.t0, T.t1, n0, n1) : hit_box(lo, hi, T.e, T.d, T.t0, T.t1, n0, n1);
                         if (hb) {
 #if !defined(RT_STEP_STATS) || RT_STEP_STATS < 3
-                            c.leaf++; c.prim += ntri;
+                            c.leaf++; c.prim += ntri; c.fp64 += ntri;
 #endif
                             T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
                         }
@@ -1297,16 +1307,21 @@ __device__ inline void camera_ray_lens(const rt_camera &c, float s, float t, uin
     d = norm(lookat - e);
 }
 
-__device__ inline void flush_counters(uint64_t *counters, const Counters &c)
+__device__ inline void flush_counters(uint64_t *counters, uint64_t *kstats, const Counters &c)
 {
-    if (!counters) return;
-    // one atomic per wave and counter: wave-reduce with cross-lane adds first
-    uint64_t v[4] = { c.rays, c.inner, c.leaf, c.prim };
+    if (!counters && !kstats) return;
+    // one atomic per wave and counter: wave-reduce with cross-lane adds first.  `counters` = the caller's
+    // four work counters, `kstats` = the launch's own block of RT_KSTAT_WORDS (profiling only)
+    uint64_t v[6] = { c.rays, c.inner, c.leaf, c.prim, c.box, c.fp64 };
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 6; k++) {
+        if (k >= 4 && !kstats) break;
         uint64_t x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long *)&counters[k], (unsigned long long)x);
+        if ((threadIdx.x & 63) == 0 && x) {
+            if (counters && k < 4) atomicAdd((unsigned long long *)&counters[k], (unsigned long long)x);
+            if (kstats) atomicAdd((unsigned long long *)&kstats[k], (unsigned long long)x);
+        }
     }
 }
 
@@ -1365,9 +1380,9 @@ RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(RaySrc src, uint32_t *next, uint64_t *counters)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(src.S, src, next, 128u, stk, c);
-    flush_counters(counters, c);
+    flush_counters(counters, nullptr, c);
 }
 
 struct PrimarySrc {         // rt_trace_primary: one ray through every pixel centre
@@ -1396,9 +1411,9 @@ RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(PrimarySrc src, uint32_t *next, uint64_t *counters)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(src.S, src, next, 128u, stk, c);
-    flush_counters(counters, c);
+    flush_counters(counters, nullptr, c);
 }
 
 // ------------------------------------------------------------------ lights
@@ -1664,12 +1679,12 @@ struct ShadowSrc {
     }
 };
 RT_TRACE_ATTR
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow(DevScene S, ShadowSrc src, uint32_t *next, uint32_t batch_max, uint64_t *counters)
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow(DevScene S, ShadowSrc src, uint32_t *next, uint32_t batch_max, uint64_t *counters, uint64_t *kstats)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
-    flush_counters(counters, c);
+    flush_counters(counters, kstats, c);
 }
 
 // Closest hit for the chunk [base, base+count) of a ray stack.
@@ -1708,9 +1723,9 @@ RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next, uint32_t batch_max)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
-    flush_counters(src.A.counters, c);
+    flush_counters(src.A.counters, src.A.kstats ? src.A.kstats + RT_KSTAT_WORDS * RT_KSTAT_ENGINE : nullptr, c);
 }
 
 // ------------------------------------------------------------------ rays that stay outside the octrees
@@ -1794,7 +1809,7 @@ __device__ __forceinline__ void sweep_rays(const DevScene &S, const Src &src, ui
             const bool done = live && !defer;
             Hit h; h.t = t1; h.obj = hobj; h.prim = hprim;
             src.store_wave(done, item, hobj >= 0, h);
-            if (done) { c.rays++; c.leaf += nleaf; c.prim += nprim; }
+            if (done) { c.rays++; c.leaf += nleaf; c.prim += nprim; c.fp64 += nprim; }
         }
         const unsigned long long dm = ballot64(defer);
         if (dm != 0ull) {
@@ -1817,31 +1832,31 @@ struct RetrySrc {
 };
 __global__ __launch_bounds__(RT_BLOCK) void k_sweep(DevScene S, StackSrc src, uint32_t *retry_count, uint32_t *retry_list)
 {
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     sweep_rays(S, src, retry_count, retry_list, c);
-    flush_counters(src.A.counters, c);
+    flush_counters(src.A.counters, src.A.kstats ? src.A.kstats + RT_KSTAT_WORDS * RT_KSTAT_SWEEP : nullptr, c);
 }
-__global__ __launch_bounds__(RT_BLOCK) void k_sweep_shadow(DevScene S, ShadowSrc src, uint32_t *retry_count, uint32_t *retry_list, uint64_t *counters)
+__global__ __launch_bounds__(RT_BLOCK) void k_sweep_shadow(DevScene S, ShadowSrc src, uint32_t *retry_count, uint32_t *retry_list, uint64_t *counters, uint64_t *kstats)
 {
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     sweep_rays(S, src, retry_count, retry_list, c);
-    flush_counters(counters, c);
+    flush_counters(counters, kstats, c);
 }
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_retry(DevScene S, RetrySrc<StackSrc> src, uint32_t *next, uint32_t batch_max)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
-    flush_counters(src.b.A.counters, c);
+    flush_counters(src.b.A.counters, src.b.A.kstats ? src.b.A.kstats + RT_KSTAT_WORDS * RT_KSTAT_SWEEP : nullptr, c);
 }
 RT_TRACE_ATTR
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow_retry(DevScene S, RetrySrc<ShadowSrc> src, uint32_t *next, uint32_t batch_max, uint64_t *counters)
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow_retry(DevScene S, RetrySrc<ShadowSrc> src, uint32_t *next, uint32_t batch_max, uint64_t *counters, uint64_t *kstats)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
-    Counters c = { 0, 0, 0, 0 };
+    Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
-    flush_counters(counters, c);
+    flush_counters(counters, kstats, c);
 }
 
 // Consume the hits of chunk [base, base+count) of `src`; follow-up rays are appended to D.
@@ -2175,13 +2190,14 @@ hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *ctrl, ui
     if (e != hipSuccess) return e;
     if (ray_class == 0) {
         RetrySrc<ShadowSrc> again = { src, retry, ctrl + 5 };
-        hipLaunchKernelGGL(k_sweep_shadow, dim3(sweep_blocks(count, num_cu)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 5, retry, A.counters);
+        hipLaunchKernelGGL(k_sweep_shadow, dim3(sweep_blocks(count, num_cu)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 5, retry, A.counters,
+                           A.kstats ? A.kstats + RT_KSTAT_WORDS * RT_KSTAT_SWEEP_SHADOW : nullptr);
         hipLaunchKernelGGL(k_trace_shadow_retry, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow_retry)), dim3(RT_BLOCK), 0, st, S, again, ctrl + 4,
-                           (uint32_t)RT_BATCH1, A.counters);
+                           (uint32_t)RT_BATCH1, A.counters, A.kstats ? A.kstats + RT_KSTAT_WORDS * RT_KSTAT_SWEEP_SHADOW : nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_trace_shadow, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4,
-                       (uint32_t)RT_BATCH1, A.counters);
+                       (uint32_t)RT_BATCH1, A.counters, A.kstats ? A.kstats + RT_KSTAT_WORDS * RT_KSTAT_ENGINE_SHADOW : nullptr);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,

@@ -20,7 +20,7 @@ EXPORTS = (
     "rt_last_error", "rt_device_count", "rt_set_device", "rt_scene_create", "rt_scene_destroy",
     "rt_scene_octree_stats", "rt_camera_init", "rt_trace_rays", "rt_trace_rays_host",
     "rt_trace_primary", "rt_trace_primary_host", "rt_ray_color", "rt_ray_color_host", "rt_ray_color_noalloc", "rt_render",
-    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_scene_get_ray_flow", "rt_scene_set_workspace_limit", "rt_scene_workspace_bytes", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
+    "rt_render_host", "rt_scene_check", "rt_scene_set_profiling", "rt_scene_get_profile", "rt_scene_get_kernel_stats", "rt_scene_get_ray_flow", "rt_scene_set_workspace_limit", "rt_scene_workspace_bytes", "rt_resolve_bgr8", "rt_resolve_bgr8_host", "rt_save_bmp",
     "rt_camera_change_fov", "rt_light_move_face", "rt_scene_set_light",
     "rt_scene_implicit_stats", "rt_scene_implicit_boxes", "rt_perlin_tables", "rt_perlin_noise",
     "rt_resolve_tone_bgr8", "rt_resolve_tone_bgr8_host", "rt_avi_open", "rt_avi_open_mjpg", "rt_avi_add_frame", "rt_avi_close",
@@ -66,6 +66,7 @@ def lib():
     L.rt_scene_set_profiling.argtypes = [_vp, _int]
     L.rt_scene_get_profile.argtypes = [_vp, _dp, _int]
     L.rt_scene_get_ray_flow.argtypes = [_vp, _dp, _int]
+    L.rt_scene_get_kernel_stats.argtypes = [_vp, _dp, _int]
     L.rt_scene_set_workspace_limit.argtypes = [_vp, _u64]
     L.rt_scene_workspace_bytes.restype = C.c_int64
     L.rt_scene_workspace_bytes.argtypes = [_vp]
@@ -301,6 +302,15 @@ class HipScene:
         out = (C.c_double * 6)()
         _chk(lib().rt_scene_get_profile(self._h, out, 1 if reset else 0), "rt_scene_get_profile")
         return dict(zip(("trace_launches", "trace_ms", "shade_launches", "shade_ms", "generate_launches", "rounds"), out[:]))
+
+    KERNEL_STAGES = ("k_trace", "k_trace_shadow", "k_sweep+k_trace_retry", "k_sweep_shadow+k_trace_shadow_retry")
+
+    def get_kernel_stats(self, reset=True):
+        """Per stage of the closest-hit search (profiling on): launches, ms, work counters, executed tests."""
+        out = (C.c_double * 40)()
+        _chk(lib().rt_scene_get_kernel_stats(self._h, out, 1 if reset else 0), "rt_scene_get_kernel_stats")
+        names = ("launches", "ms", "rays", "inner", "leaf", "prim", "box_tests", "fp64_tests")
+        return {st: dict(zip(names, out[10 * i:10 * i + 8])) for i, st in enumerate(self.KERNEL_STAGES)}
 
     def get_ray_flow(self, reset=True):
         out = (C.c_double * 6)()
