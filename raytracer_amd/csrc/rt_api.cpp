@@ -383,6 +383,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         if (prim >= 0xFFFFFFFFull) return fail("rt_scene_create: more than 2^32-1 primitives");
     }
 
+    for (uint64_t i = 0; i < d->nobjects; i++) {
+        const bool chain = i + 1 < d->nobjects && objs[i].type == RT_OBJ_MESH && objs[i].ntri == 0 && objs[i + 1].type == RT_OBJ_MESH && objs[i + 1].ntri == 0;
+        objs[i].next_root = chain ? objs[i + 1].root : RT_NO_CHAIN;
+    }
+
     rt_scene *s = new (std::nothrow) rt_scene;
     if (!s) return fail("rt_scene_create: out of memory");
     hipError_t e = hipGetDevice(&s->device);
@@ -495,6 +500,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.nobjects = (int32_t)d->nobjects;
     s->dev.nlights = (int32_t)d->nlights;
     s->dev.regular = 1;
+    s->dev.any_chain = 0;
+    for (const DevObject &q : objs) if (q.next_root != RT_NO_CHAIN) s->dev.any_chain = 1;
     s->dev.nbig = 0;
     {
         // what one sweep over the objects costs, in box-test units: one per object, two per triangle

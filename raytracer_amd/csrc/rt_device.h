@@ -32,12 +32,14 @@ struct DevObject {
     int32_t  material;
     uint32_t tri_base;   // mesh: index of its first triangle record
     uint32_t prim_base;  // global primitive id of the object's first primitive
-    uint32_t pad0;
+    uint32_t next_root;  // root of the next object's octree if that object is a mesh with inner nodes, else RT_NO_CHAIN:
+                         // a lane that finishes this object's octree goes straight on to that root
     double   p[4];       // sphere: centre, radius; plane: coordinate
     double   lo[3], hi[3];   // mesh with ntri != 0: the root's box
     double   pad1[2];
 };
 static_assert(sizeof(DevObject) == 128, "DevObject must be 128 bytes");
+#define RT_NO_CHAIN 0xFFFFFFFFu
 
 struct DevScene {
     const DevObject   *objects;
@@ -60,7 +62,7 @@ struct DevScene {
     double  background[3];
     float   big_lo[4][3], big_hi[4][3];
     int32_t shade_kinds;           // material features the objects use: 1 mirror lobe, 2 dielectric lobe, 4 Phong / Perlin / check (any of these: 7)
-    int32_t pad;
+    int32_t any_chain;             // some object has a next_root (see DevObject)
 };
 
 enum { RT_MAX_BIG = 4 };

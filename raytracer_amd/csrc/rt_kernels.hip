@@ -913,7 +913,9 @@ __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 //
 // The step kinds are nested loops (object phase outermost, triangle phase innermost) so that the
 // state a phase does not touch stays put in its registers while that phase repeats.
-template <int BLOCK, class Src>
+// CHAIN: lanes go from one octree straight on to the next object's (see `chain` below; scenes with several
+// octrees in a row); it never changes a result, and kernels compiled without it are leaner.
+template <int BLOCK, bool CHAIN = false, class Src>
 __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t *next, uint32_t batch_max,
                                     uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
 {
@@ -962,6 +964,17 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
             mode = TM_NODE;
             break;
         }
+    };
+    // A lane whose octree is finished and whose next object is an octree with inner nodes as well goes
+    // straight on to that octree's root, without waiting for an object phase: Octree::hit's verdict
+    // (octree.cpp:371-375), then the next child of the group (Surface.cpp:160-181).
+    auto chain = [&]() {
+        if (T.oi & RT_OI_LOCAL) return;
+        const uint32_t nr = S.objects[T.oi].next_root;
+        if (nr == RT_NO_CHAIN) return;
+        if (T.minprim != RT_MISS && T.mint <= T.t1) { T.t1 = T.mint; T.hobj = T.oi; T.hprim = T.minprim; }
+        T.oi++;
+        T.root = nr; T.cur = nr; T.sp = 0; T.mint = T.t1 + 1; T.minprim = RT_MISS; mode = TM_NODE;
     };
     for (;;) {
         // ---------------------------------------------------------------- object phase
@@ -1147,6 +1160,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
                 const bool in = mode == TM_NODE;
                 if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
                 else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
+                if (CHAIN && ((mN >> lane) & 1ull) && mode == TM_OBJ) chain();
                 RT_TICK(inner)
                 continue;
             }
@@ -1162,6 +1176,7 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
             }
 #endif
             tri_phase<BLOCK>(S, T, mode, run_bt1, rayf, coop[tid >> 6], c);
+            if (CHAIN && ((mT >> lane) & 1ull) && mode == TM_OBJ) chain();
             RT_TICK(leaf)
         }
         if (finished) break;
@@ -1678,12 +1693,13 @@ struct ShadowSrc {
         add_radiance_wave(out, add, pix, v);
     }
 };
+template <bool CHAIN>
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow(DevScene S, ShadowSrc src, uint32_t *next, uint32_t batch_max, uint64_t *counters, uint64_t *kstats)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
-    trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
+    trace_engine<RT_BLOCK, CHAIN>(S, src, next, batch_max, stk, c);
     flush_counters(counters, kstats, c);
 }
 
@@ -1719,12 +1735,13 @@ struct StackSrc {
         q.hit_id[slot] = hit ? (((uint64_t)(uint32_t)h.obj << 32) | h.prim) : ~0ull;
     }
 };
+template <bool CHAIN>
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next, uint32_t batch_max)
 {
     __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
-    trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
+    trace_engine<RT_BLOCK, CHAIN>(S, src, next, batch_max, stk, c);
     flush_counters(src.A.counters, src.A.kstats ? src.A.kstats + RT_KSTAT_WORDS * RT_KSTAT_ENGINE : nullptr, c);
 }
 
@@ -2178,7 +2195,8 @@ hipError_t launch_trace(const DevScene &S, int num_cu, uint32_t *ctrl, uint32_t 
         hipLaunchKernelGGL(k_trace_retry, dim3(engine_blocks(count, num_cu, (const void *)k_trace_retry)), dim3(RT_BLOCK), 0, st, S, again, ctrl + 4, (uint32_t)RT_BATCH1);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_trace, dim3(engine_blocks(count, num_cu, (const void *)k_trace)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4, (uint32_t)RT_BATCH1);
+    if (S.any_chain) hipLaunchKernelGGL(k_trace<true>, dim3(engine_blocks(count, num_cu, (const void *)k_trace<true>)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4, (uint32_t)RT_BATCH1);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(engine_blocks(count, num_cu, (const void *)k_trace<false>)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4, (uint32_t)RT_BATCH1);
     return hipGetLastError();
 }
 hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *ctrl, uint32_t *retry, const WaveArgs &A, const ShadowStack &q, uint64_t base,
@@ -2196,8 +2214,11 @@ hipError_t launch_trace_shadow(const DevScene &S, int num_cu, uint32_t *ctrl, ui
                            (uint32_t)RT_BATCH1, A.counters, A.kstats ? A.kstats + RT_KSTAT_WORDS * RT_KSTAT_SWEEP_SHADOW : nullptr);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_trace_shadow, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4,
-                       (uint32_t)RT_BATCH1, A.counters, A.kstats ? A.kstats + RT_KSTAT_WORDS * RT_KSTAT_ENGINE_SHADOW : nullptr);
+    uint64_t *const ks = A.kstats ? A.kstats + RT_KSTAT_WORDS * RT_KSTAT_ENGINE_SHADOW : nullptr;
+    if (S.any_chain) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow<true>)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4,
+                                        (uint32_t)RT_BATCH1, A.counters, ks);
+    else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(engine_blocks(count, num_cu, (const void *)k_trace_shadow<false>)), dim3(RT_BLOCK), 0, st, S, src, ctrl + 4,
+                            (uint32_t)RT_BATCH1, A.counters, ks);
     return hipGetLastError();
 }
 hipError_t launch_shade(const DevScene &S, const WaveArgs &A, const RayStack &src, uint64_t base, uint32_t count,
