@@ -1905,16 +1905,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene S, WaveArgs A, RayS
         if (!hit) sum = had(W, ld3(S.background));                           // scene.cpp:196-198, 378-380
         else shade = true;
     }
-    // values every push site needs; misses skip these loads
-    V3 re = mk(0, 0, 0), rd = mk(0, 0, 1);
-    uint64_t key = 0;
-    double ht = 0;
-    if (shade) {
-        re = mk(ray_f(src, slot, RAY_EX), ray_f(src, slot, RAY_EY), ray_f(src, slot, RAY_EZ));
-        rd = mk(ray_f(src, slot, RAY_DX), ray_f(src, slot, RAY_DY), ray_f(src, slot, RAY_DZ));
-        key = src.f[(uint64_t)RAY_KEY * src.cap + slot];
-        ht = src.hit_t[slot];
-    }
+    // values every push site needs, asked for together with the fields above (a miss reads them for
+    // nothing, but a hit does not wait a second time)
+    V3 re = mk(ray_f(src, slot, RAY_EX), ray_f(src, slot, RAY_EY), ray_f(src, slot, RAY_EZ));
+    V3 rd = mk(ray_f(src, slot, RAY_DX), ray_f(src, slot, RAY_DY), ray_f(src, slot, RAY_DZ));
+    uint64_t key = src.f[(uint64_t)RAY_KEY * src.cap + slot];
+    double ht = src.hit_t[slot];
+    if (!shade) { re = mk(0, 0, 0); rd = mk(0, 0, 1); key = 0; ht = 0; }
     const int jt = jump + 1;
     Hit h; h.t = ht; h.obj = (int32_t)(id >> 32); h.prim = (uint32_t)id;
     if (!shade) { h.obj = 0; h.prim = 0; }

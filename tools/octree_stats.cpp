@@ -171,7 +171,7 @@ int main(int argc, char **argv)
     const int MAXD = 16;
     std::vector<Stats> byDepth(MAXD + 1);
     std::vector<Stats> byLen(12);     // run length buckets: log2
-    double nrays = 0, ninner = 0, nleaf = 0;
+    double nrays = 0, ninner = 0, nleaf = 0, nempty = 0, nempty_nohit = 0, ninner_noobj = 0;
     std::mt19937_64 rng(1);
     std::uniform_real_distribution<double> U(0, 1);
 
@@ -193,6 +193,8 @@ int main(int argc, char **argv)
                 double n0, n1;
                 if (!hit_box(n.lo, n.hi, e, d, t0, t1, n0, n1)) continue;
                 if (n.child_base) ninner++; else nleaf++;
+                if (!n.child_base && !n.obj_count) { nempty++; if (minrec == ~0u) nempty_nohit++; }
+                if (n.child_base && !n.obj_count) ninner_noobj++;
                 bool improved = false;
                 if (n.obj_count) {
                     Stats &S = byDepth[std::min(T.depth[en.node], MAXD)];
@@ -273,7 +275,7 @@ int main(int argc, char **argv)
                 e = p;
             }
         }
-    printf("rays %.0f  inner/ray %.2f  leaf/ray %.2f\n", nrays, ninner / nrays, nleaf / nrays);
+    printf("rays %.0f  inner/ray %.2f  leaf/ray %.2f  empty leaves/ray %.2f (before any hit: %.2f)  inner without objects/ray %.2f\n", nrays, ninner / nrays, nleaf / nrays, nempty / nrays, nempty_nohit / nrays, ninner_noobj / nrays);
     auto row = [&](const char *name, int k, const Stats &S) {
         if (!S.visits) return;
         printf("%s %2d: visits/ray %6.3f run-box pass %5.1f%% recs/ray %7.2f cand %6.2f hit %5.2f |", name, k, S.visits / nrays, 100 * S.runpass / S.visits, S.recs / nrays, S.cand / nrays, S.hits / nrays);
