@@ -46,8 +46,68 @@ def shell_rays(rng, n, radius, target):
     return r
 
 
+def edge_cases():
+    """Constructed inputs for branches that random draws do not reach:
+    Sphere::hit's tangent branch, which skips the [t0, t1] window (Surface.cpp:79-81) -- discriminants
+    of exactly zero and of magnitude below / above 1e-9, with the tangent point inside and outside the
+    window; SphereLight::getPosition's two "do not sample" exits (light.cpp:146-149: the shading point
+    on the light's surface, light.cpp:153-156: cosmax >= 1 - 1e-9) with points on either side of both
+    thresholds; the planes with the ray's origin exactly on, just above and just below the plane
+    (Surface.cpp:124-133, 194-204, 217-226)."""
+    # spheres with exactly representable centre / radius; rays along an axis that pass the centre at a
+    # distance of radius + delta, so that the discriminant is (close to) -2 * radius * delta * |d|^2
+    sc, sr, se, sd, st0, st1, sout = [], [], [], [], [], [], []
+    for c, r in (((0.0, 0.0, 0.0), 1.0), ((2.0, -4.0, 8.0), 0.5), ((-16.0, 32.0, 1.0), 4.0)):
+        for axis in range(3):
+            for scale in (1.0, 2.0, 0.25):
+                for delta in (0.0, 1e-11, -1e-11, 2e-10, -2e-10, 4e-10 / r, -4e-10 / r, 3e-9, -3e-9, 1e-6, -1e-6):
+                    off = (axis + 1) % 3
+                    e = np.array(c, float); e[axis] -= 5.0; e[off] += r + delta
+                    d = np.zeros(3); d[axis] = scale
+                    tt = 5.0 / scale                              # the tangent point's parameter
+                    for t0, t1 in ((1e-9, 1e10), (1e-9, tt - 0.5), (tt + 0.5, 1e10), (1e-9, tt), (tt, 1e10)):
+                        h, t, nn = orc.ref_sphere_hit(c, r, e, d, t0, t1)
+                        sc.append(c); sr.append(r); se.append(e); sd.append(d); st0.append(t0); st1.append(t1)
+                        sout.append((h, t if h else 0.0, *(nn if h else (0, 0, 0))))
+    # sphere lights: shading points at distance radius + delta from the centre, and far points around
+    # the distance where cosmax reaches 1 - 1e-9 (radius / distance = sqrt(2e-9) = 4.47e-5)
+    lp, lr, lx, luv, lout = [], [], [], [], []
+    for pos, r in (((0.0, 0.0, 0.0), 1.0), ((4.0, 8.0, -2.0), 0.5), ((-3.0, 1.0, 64.0), 2.0)):
+        dirs = [np.array(v, float) for v in ((1, 0, 0), (0, -1, 0), (0, 0, 1), (0.6, 0.8, 0.0), (0.0, -0.6, 0.8))]
+        for dv in dirs:
+            for delta in (0.0, 5e-10, -5e-10, 9e-10, 2e-9, -2e-9, 1e-6, -1e-6):
+                lp.append(pos); lr.append(r); lx.append(np.array(pos) + dv * (r + delta)); luv.append((0.3, 0.7))
+            for ratio in (1e-6, 2e-5, 4.4e-5, 4.4721e-5, 4.4722e-5, 4.5e-5, 6e-5, 1e-3):
+                lp.append(pos); lr.append(r); lx.append(np.array(pos) + dv * (r / ratio)); luv.append((0.62, 0.18))
+    for i in range(len(lp)):
+        p, nl, pdf = orc.ref_sphere_light_sample(lp[i], lr[i], lx[i], luv[i][0], luv[i][1])
+        lout.append((*p, *nl, pdf))
+    # planes: the origin's coordinate on the plane's axis is coord + delta
+    pk, pc, pe, pd, pt0, pt1, pout = [], [], [], [], [], [], []
+    for kind, axis in ((2, 1), (3, 2), (4, 0)):                    # Ground (y), Wall_z, Wall_x
+        for coord in (0.0, 1.5, -8.0):
+            for delta in (0.0, 1e-300, 5e-324, 1e-12, 5e-10, 2e-9, -1e-12, -1.0, 2.0):
+                for dcomp in (-1.0, -1e-9, -0.0, 0.0, 1e-9, 1.0):
+                    e = np.array([0.3, 0.4, 0.5]); e[axis] = coord + delta
+                    d = np.array([0.2, 0.3, 0.1]); d[axis] = dcomp
+                    for t0, t1 in ((1e-9, 1e10), (0.0, 1e10), (1e-9, 1.0)):
+                        h, t, nn = orc.ref_plane_hit(kind, coord, e, d, t0, t1)
+                        pk.append(kind); pc.append(coord); pe.append(e); pd.append(d); pt0.append(t0); pt1.append(t1)
+                        pout.append((h, t if h else 0.0))
+    np.savez_compressed(os.path.join(HERE, "edge_cases.npz"),
+                        sph_c=np.array(sc), sph_r=np.array(sr), sph_e=np.array(se), sph_d=np.array(sd), sph_t0=np.array(st0), sph_t1=np.array(st1), sph_out=np.array(sout, float),
+                        light_pos=np.array(lp), light_r=np.array(lr), light_x=np.array(lx), light_uv=np.array(luv), light_out=np.array(lout, float),
+                        pl_kind=np.array(pk), pl_coord=np.array(pc), pl_e=np.array(pe), pl_d=np.array(pd), pl_t0=np.array(pt0), pl_t1=np.array(pt1), pl_out=np.array(pout, float))
+    so = np.array(sout, float); lo_ = np.array(lout, float)
+    print("edge cases: sphere", len(sout), "hits", int(so[:, 0].sum()), "| light", len(lout), "skipped", int((lo_[:, 6] > 1e10).sum()),
+          "nan", int(np.isnan(lo_).any(axis=1).sum()), "| plane", len(pout), "hits", int(np.array(pout)[:, 0].sum()))
+
+
 def main():
     assert orc.ref_available(), "build oracle/_ref first (make -C oracle)"
+    if len(sys.argv) > 1 and sys.argv[1] == "edge":
+        edge_cases()
+        return
     rng = np.random.default_rng(20260101)
 
     # 1. hitBox (algorithms.h:223-236)
@@ -202,6 +262,8 @@ def main():
         lpos.append(pos); lsample.append(smp)
         tt += 0.015
     np.savez_compressed(os.path.join(HERE, "animation.npz"), times=np.array(times), cams=np.stack(cams), light_pos=np.stack(lpos), light_sample=np.stack(lsample))
+    # 12. constructed edge cases
+    edge_cases()
     print("golden vectors written to", HERE)
 
 

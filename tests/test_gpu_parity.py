@@ -106,6 +106,77 @@ def test_group_hit_matches_reference_golden(golden_dir):
     assert np.array_equal(t[hit], g["t"][hit]) and np.array_equal(nrm[hit], g["normal"][hit])
 
 
+def test_reference_edge_branches_on_device(golden_dir):
+    """The constructed edge cases of the golden vectors through the kernels: tangent rays, whose hit is
+    reported whatever the window (Surface.cpp:79-81), and rays that start on a plane
+    (Surface.cpp:124-133, 194-204, 217-226) -- distances bit for bit the reference's; the two "do not
+    sample" exits of SphereLight::getPosition (light.cpp:146-156) through per-path radiance."""
+    g = _load(golden_dir, "edge_cases")
+    mats = scenes._stack([scenes.material(MAT_NORMAL, color=(.5, .5, .5))], MATERIAL_DT)
+    groups = {}
+    for i in range(len(g["sph_out"])):
+        groups.setdefault((tuple(g["sph_c"][i]), float(g["sph_r"][i]), float(g["sph_t0"][i]), float(g["sph_t1"][i])), []).append(i)
+    outside = 0
+    scene_of = {}
+    for (c, r, t0, t1), idx in groups.items():
+        if (c, r) not in scene_of:
+            scene_of[(c, r)] = hip.HipScene(SceneDesc(scenes._stack([scenes.sphere(c, r, 0)], OBJECT_DT), mats, np.zeros(0, LIGHT_DT), []))
+        rays = np.zeros(len(idx), RAY_DT); rays["e"] = g["sph_e"][idx]; rays["d"] = g["sph_d"][idx]
+        prim, t, nrm, _ = scene_of[(c, r)].trace_rays(rays, t0, t1)
+        exp = g["sph_out"][idx]
+        assert np.array_equal(prim != MISS, exp[:, 0] > 0)
+        hit = exp[:, 0] > 0
+        assert np.array_equal(t[hit], exp[hit, 1]) and np.array_equal(nrm[hit], exp[hit, 2:5])
+        outside += int(((t[hit] < t0) | (t[hit] > t1)).sum())
+    assert outside > 100
+    groups = {}
+    for i in range(len(g["pl_out"])):
+        groups.setdefault((int(g["pl_kind"][i]), float(g["pl_coord"][i]), float(g["pl_t0"][i]), float(g["pl_t1"][i])), []).append(i)
+    scene_of = {}
+    hits = 0
+    for (kind, coord, t0, t1), idx in groups.items():
+        if (kind, coord) not in scene_of:
+            scene_of[(kind, coord)] = hip.HipScene(SceneDesc(scenes._stack([scenes.plane(kind, coord, 0)], OBJECT_DT), mats, np.zeros(0, LIGHT_DT), []))
+        rays = np.zeros(len(idx), RAY_DT); rays["e"] = g["pl_e"][idx]; rays["d"] = g["pl_d"][idx]
+        prim, t, _, _ = scene_of[(kind, coord)].trace_rays(rays, t0, t1)
+        exp = g["pl_out"][idx]
+        hit = exp[:, 0] > 0
+        assert np.array_equal(prim != MISS, hit) and np.array_equal(t[hit], exp[hit, 1])
+        hits += int(hit.sum())
+    assert hits > 50
+    # light.cpp:146-149: a ray that hits the light's own sphere is shaded on the light's surface, where the
+    # light is not sampled: the path returns the sphere's emission and nothing else, on both sides alike
+    lmats = scenes._stack([scenes.material(MAT_NORMAL, color=(.6, .6, .6)), scenes.material(MAT_NORMAL, emission=(7, 5, 3), color=(0, 0, 0))], MATERIAL_DT)
+    desc = SceneDesc(scenes._stack([scenes.plane(OBJ_GROUND, 0.0, 0), scenes.sphere((0, 3, 0), 1.0, 1)], OBJECT_DT), lmats,
+                     scenes._stack([scenes.sphere_light((0, 3, 0), 1.0, (7, 5, 3))], LIGHT_DT), [], background=(0, 0, 0))
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    rng = np.random.default_rng(5)
+    n = 4000
+    rays = np.zeros(n, RAY_DT)
+    rays["e"] = rng.normal(size=(n, 3)); rays["e"] *= 6.0 / np.linalg.norm(rays["e"], axis=1, keepdims=True); rays["e"] += (0, 3, 0)
+    d = (0, 3, 0) + rng.uniform(-0.6, 0.6, (n, 3)) - rays["e"]
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    prm = render_params(64, 64, 1, seed=3)
+    c1, k1 = so.ray_color(rays, prm)
+    c2, k2 = sg.ray_color(rays, prm)
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2)
+    assert np.array_equal(c2, np.tile((7.0, 5.0, 3.0), (n, 1)))
+    # light.cpp:153-156: a light so small and far that cosmax >= 1 - 1e-9 is not sampled either: the ground
+    # under it stays black, while the same light a little larger lights it
+    for radius, lit in ((1e-3, False), (1e-2, True)):
+        desc = SceneDesc(scenes._stack([scenes.plane(OBJ_GROUND, 0.0, 0), scenes.sphere((0, 50, 0), radius, 1)], OBJECT_DT), lmats,
+                         scenes._stack([scenes.sphere_light((0, 50, 0), radius, (7e6, 5e6, 3e6))], LIGHT_DT), [], background=(0, 0, 0))
+        so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+        rays = np.zeros(n, RAY_DT)
+        rays["e"] = rng.uniform(-3, 3, (n, 3)) + (0, 6, 0)
+        d = rng.uniform(-4, 4, (n, 3)) * (1, 0, 1) - rays["e"]
+        rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        c1, k1 = so.ray_color(rays, prm)
+        c2, k2 = sg.ray_color(rays, prm)
+        assert np.array_equal(k1, k2) and _rel(c1, c2).max() <= PATH_RTOL
+        assert (c2.max() > 0) == lit
+
+
 @pytest.mark.parametrize("seed,ntri,max_size,edge", [(31, 30000, 128, (3e-3, 5e-2)), (32, 4000, 8, (1e-2, 1e-1)),
                                                      (33, 200, 128, (1e-2, 3e-1)), (34, 60000, 32, (1e-3, 2e-2)),
                                                      (35, 0, 128, (1e-2, 1e-1)), (36, 1, 128, (2e-1, 5e-1))])
@@ -123,12 +194,12 @@ def test_trace_rays_bit_exact_vs_oracle(seed, ntri, max_size, edge):
 
 
 @pytest.mark.parametrize("case", ["far", "slivers", "flat", "mixed_sizes", "on_split_planes"])
-def test_sphere_pretest_never_rejects_a_hit(case):
-    """The single-precision sphere pre-test works in a per-node integer grid; geometry that is hard
+def test_box_pretest_never_rejects_a_hit(case):
+    """The single-precision box pre-test works in a per-node integer grid; geometry that is hard
     on it must still give the oracle's ids, distances and test counts bit for bit: a mesh far from
     the origin (coordinates 1e8 times the triangle size), needle triangles, a mesh with no extent
     along one axis, triangles from 1e-4 to 1 of the mesh's size in one octree, and walls across the
-    whole mesh that lie exactly in the octree's splitting planes (a record's sphere bounds the part
+    whole mesh that lie exactly in the octree's splitting planes (a record's box bounds the part
     of its triangle inside the node's box: here that part is a face of the box)."""
     rng = np.random.default_rng(91)
     if case == "far":
@@ -662,7 +733,7 @@ def test_perlin_materials(golden_dir, tables):
     p1, t1, n1, c1 = so.trace_rays(rays, 0.0, 1e10)
     p2, t2, n2, c2 = sg.trace_rays(rays, 0.0, 1e10)
     assert np.array_equal(p1, p2) and np.array_equal(t1, t2) and np.array_equal(c1, c2)
-    assert np.abs(n1 - n2).max() <= 1e-9              # floor / fabs / sqrt are exact; tolerance for the device's division by `scale`
+    assert np.array_equal(n1, n2)                     # the tilted normals too: division, floor, fabs and sqrt are exact on both sides
     prm = render_params(W, H, 1, seed=41, max_jump=10)
     a1, k1 = so.ray_color(rays, prm)
     a2, k2 = sg.ray_color(rays, prm)

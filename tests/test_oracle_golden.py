@@ -106,6 +106,49 @@ def test_lights_bit_exact(golden_dir):
     assert skipped < n // 2
 
 
+def test_constructed_edge_cases_bit_exact(golden_dir):
+    """Branches that random inputs do not reach, with inputs built for them and the reference's own
+    answers (tests/golden/make_golden.py, edge_cases): Sphere::hit's tangent branch, which reports a
+    tangent point whatever the window (Surface.cpp:79-81), for discriminants of zero and on either
+    side of 1e-9; SphereLight::getPosition's two "do not sample" exits (light.cpp:146-149, 153-156)
+    with points on either side of both thresholds; planes with the origin on the plane
+    (Surface.cpp:124-133, 194-204, 217-226)."""
+    g = _load(golden_dir, "edge_cases")
+    o = g["sph_out"]
+    outside = 0
+    for i in range(len(o)):
+        t0, t1 = float(g["sph_t0"][i]), float(g["sph_t1"][i])
+        h, t = orc.sphere_hit(g["sph_c"][i], float(g["sph_r"][i]), g["sph_e"][i], g["sph_d"][i], t0, t1)
+        assert h == int(o[i, 0])
+        if h:
+            assert t == o[i, 1]
+            outside += int(t < t0 or t > t1)
+    assert outside > 100                       # tangent points reported although the window excludes them
+    skipped = nans = 0
+    for i in range(len(g["light_pos"])):
+        l = np.zeros((), LIGHT_DT)
+        l["type"], l["pos"], l["radius"] = LIGHT_SPHERE, g["light_pos"][i], g["light_r"][i]
+        p, nl, pdf = orc.light_sample(l, g["light_x"][i], float(g["light_uv"][i, 0]), float(g["light_uv"][i, 1]))
+        exp, got = g["light_out"][i], np.concatenate([p, nl, [pdf]])
+        if exp[6] > 1e10:
+            skipped += 1
+            assert pdf > 1e10
+        elif np.isnan(exp).any():              # a point inside the light: NaN on both sides
+            nans += 1
+            assert np.isnan(got).any()
+        else:
+            assert np.array_equal(got, exp)
+    assert skipped > 50 and nans > 10 and skipped + nans < len(g["light_pos"])
+    hits = 0
+    for i in range(len(g["pl_kind"])):
+        h, t = orc.plane_hit(int(g["pl_kind"][i]), float(g["pl_coord"][i]), g["pl_e"][i], g["pl_d"][i], float(g["pl_t0"][i]), float(g["pl_t1"][i]))
+        assert h == int(g["pl_out"][i, 0])
+        if h:
+            hits += 1
+            assert t == g["pl_out"][i, 1]
+    assert hits > 50
+
+
 @pytest.mark.parametrize("name", ["octree_soup_a", "octree_soup_b"])
 def test_octree_build_and_traversal_bit_exact(golden_dir, name):
     g = _load(golden_dir, name)
