@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_device.h"
@@ -248,10 +249,36 @@ int rt_scene_destroy(rt_scene *s)
     return 0;
 }
 
-int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
+// Everything rt_scene_create derives from a scene description on the host, ready to be copied to a
+// device: the octrees (built once, whatever the number of devices), their records and boxes, the
+// object table.
+struct HostScene {
+    std::vector<DevObject> objs;
+    std::vector<rt_material> mats;
+    std::vector<rt_light> lights;
+    std::vector<FlatNode> nodes;
+    std::vector<LeafTri> leaf_tris;
+    std::vector<double> tris, tri_normals;
+    std::vector<uint32_t> leaf_box, seg_box, run_box;
+    std::vector<int32_t> perlin_p;
+    std::vector<double> perlin_g;
+    std::vector<MeshInfo> infos;
+    MeshInfo implicit_info[2] = {};
+    std::vector<double> implicit_boxes[2];
+    bool has_implicit[2] = {false, false};
+    uint64_t nobjects = 0, nlights = 0;
+    double background[3] = {0, 0, 0};
+};
+
+static int assemble_scene(const rt_scene_desc *d, HostScene &H)
 {
-    if (!d || !out) return fail("rt_scene_create: null argument");
-    *out = nullptr;
+    if (!d) return fail("rt_scene_create: null argument");
+    auto &nodes = H.nodes; auto &leaf_tris = H.leaf_tris; auto &tris = H.tris; auto &infos = H.infos;
+    auto &perlin_p = H.perlin_p; auto &perlin_g = H.perlin_g; auto &objs = H.objs;
+    auto &implicit_info = H.implicit_info; auto &implicit_boxes = H.implicit_boxes; auto &has_implicit = H.has_implicit;
+    auto &tri_normals = H.tri_normals; auto &leaf_box = H.leaf_box; auto &seg_box = H.seg_box; auto &run_box = H.run_box;
+    H.nobjects = d->nobjects; H.nlights = d->nlights;
+    for (int k = 0; k < 3; k++) H.background[k] = d->background[k];
     if ((d->nobjects && !d->objects) || (d->nmaterials && !d->materials) || (d->nlights && !d->lights) || (d->nmeshes && !d->meshes))
         return fail("rt_scene_create: null array with non-zero count");
     if (d->nobjects > 1u << 20 || d->nlights > 1024) return fail("rt_scene_create: too many objects or lights");
@@ -274,8 +301,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         }
         if (m.check < RT_CHECK_NONE || m.check > RT_CHECK_POSITION) return fail("rt_scene_create: unknown check material kind");
     }
-    std::vector<int32_t> perlin_p;
-    std::vector<double> perlin_g;
     if (need_perlin) {
         const bool given = d->perlin_p && d->perlin_g && d->perlin_n > 0;
         const int n = given ? d->perlin_n : 256;
@@ -294,12 +319,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     }
 
     // one octree per mesh, concatenated into scene-wide arrays
-    std::vector<FlatNode> nodes;
-    std::vector<LeafTri> leaf_tris;
-    std::vector<double> tris;
     std::vector<uint32_t> mesh_root(d->nmeshes), mesh_tri_base(d->nmeshes);
     std::vector<uint64_t> mesh_ntris(d->nmeshes);
-    std::vector<MeshInfo> infos(d->nmeshes);
+    infos.assign(d->nmeshes, MeshInfo{});
     for (uint64_t mi = 0; mi < d->nmeshes; mi++) {
         const rt_mesh &m = d->meshes[mi];
         if (m.ntris && !m.tris) return fail("rt_scene_create: mesh with null triangle array");
@@ -326,9 +348,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     // one voxel octree per kind of implicit surface present
     uint32_t implicit_root[2] = {0, 0};
     uint64_t implicit_count[2] = {0, 0};
-    MeshInfo implicit_info[2] = {};
-    std::vector<double> implicit_boxes[2];
-    bool has_implicit[2] = {false, false};
     for (uint64_t i = 0; i < d->nobjects; i++) {
         const int k = d->objects[i].type - RT_OBJ_HEART;
         if (k < 0 || k > 1 || has_implicit[k]) continue;
@@ -353,7 +372,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     }
     if (tris.size() / 9 >= (uint64_t)LEAF_VOXEL) return fail("rt_scene_create: too many triangles");
 
-    std::vector<DevObject> objs(d->nobjects);
+    objs.assign(d->nobjects, DevObject{});
     uint64_t prim = 0;
     for (uint64_t i = 0; i < d->nobjects; i++) {
         const rt_object &o = d->objects[i];
@@ -388,18 +407,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         objs[i].next_root = chain ? objs[i + 1].root : RT_NO_CHAIN;
     }
 
-    rt_scene *s = new (std::nothrow) rt_scene;
-    if (!s) return fail("rt_scene_create: out of memory");
-    hipError_t e = hipGetDevice(&s->device);
-    if (e == hipSuccess) {
-        hipDeviceProp_t prop;
-        e = hipGetDeviceProperties(&prop, s->device);
-        if (e == hipSuccess) s->num_cu = prop.multiProcessorCount;
-    }
-    std::vector<rt_material> mats(d->materials, d->materials + d->nmaterials);
-    std::vector<rt_light> lights(d->lights, d->lights + d->nlights);
+    H.mats.assign(d->materials, d->materials + d->nmaterials);
+    H.lights.assign(d->lights, d->lights + d->nlights);
     // geometric normals: Vec3::operator^ and normalize as the kernels' cross / norm evaluate them
-    std::vector<double> tri_normals(tris.size() / 3);
+    tri_normals.assign(tris.size() / 3, 0.0);
     for (size_t i = 0; i < tris.size() / 9; i++) {
         const double *l = &tris[9 * i + 3], *r = &tris[9 * i + 6];
         const double n[3] = {l[1] * r[2] - r[1] * l[2], l[2] * r[0] - l[0] * r[2], l[0] * r[1] - r[0] * l[1]};
@@ -417,9 +428,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     // octree.cpp:61-99), so "the later of two equal hits" (octree.cpp:31) is the one with the larger index
     // and the kernels can settle ties by index whatever the order of the records.  The run of a mesh whose
     // whole octree is one leaf keeps its order: the object sweep walks it record by record.
-    std::vector<uint32_t> leaf_box((leaf_tris.size() + RT_SPH_SPARE) * 2);
-    std::vector<uint32_t> seg_box((leaf_tris.size() / RT_SEG_RECS + nodes.size() + 2) * 2);
-    std::vector<uint32_t> run_box(nodes.size() * 2 + 2);          // per node: the union of its run's boxes
+    leaf_box.assign((leaf_tris.size() + RT_SPH_SPARE) * 2, 0u);
+    seg_box.assign((leaf_tris.size() / RT_SEG_RECS + nodes.size() + 2) * 2, 0u);
+    run_box.assign(nodes.size() * 2 + 2, 0u);                     // per node: the union of its run's boxes
     for (size_t i = 0; i < leaf_box.size() / 2; i++) store_whole_node_box(&leaf_box[2 * i]);
     for (size_t i = 0; i < seg_box.size() / 2; i++) store_whole_node_box(&seg_box[2 * i]);
     std::vector<bool> keep_order(nodes.size(), false);
@@ -471,6 +482,24 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
         }
         store_grid_box(&run_box[ni * 2], rlo, rhi);
     }
+    return 0;
+}
+
+// The scene on the current device: one allocation per array, the handle owns them all.
+static int upload_scene(const HostScene &H, rt_scene **out)
+{
+    *out = nullptr;
+    const auto &objs = H.objs; const auto &mats = H.mats; const auto &lights = H.lights; const auto &nodes = H.nodes;
+    const auto &leaf_tris = H.leaf_tris; const auto &tri_normals = H.tri_normals; const auto &leaf_box = H.leaf_box;
+    const auto &seg_box = H.seg_box; const auto &run_box = H.run_box; const auto &perlin_p = H.perlin_p; const auto &perlin_g = H.perlin_g;
+    rt_scene *s = new (std::nothrow) rt_scene;
+    if (!s) return fail("rt_scene_create: out of memory");
+    hipError_t e = hipGetDevice(&s->device);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, s->device);
+        if (e == hipSuccess) s->num_cu = prop.multiProcessorCount;
+    }
     void *p_obj = nullptr, *p_mat = nullptr, *p_light = nullptr, *p_nodes = nullptr, *p_idx = nullptr, *p_tris = nullptr, *p_sph = nullptr;
     void *p_pp = nullptr, *p_pg = nullptr, *p_seg = nullptr, *p_run = nullptr;
     auto up = [&](auto &vec, void **dst) {
@@ -497,8 +526,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     s->dev.perlin_p = (const int32_t *)p_pp;
     s->dev.perlin_g = (const double *)p_pg;
     s->dev.perlin_n = (int32_t)perlin_p.size();
-    s->dev.nobjects = (int32_t)d->nobjects;
-    s->dev.nlights = (int32_t)d->nlights;
+    s->dev.nobjects = (int32_t)H.nobjects;
+    s->dev.nlights = (int32_t)H.nlights;
     s->dev.regular = 1;
     s->dev.any_chain = 0;
     for (const DevObject &q : objs) if (q.next_root != RT_NO_CHAIN) s->dev.any_chain = 1;
@@ -538,15 +567,15 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
             const double a = std::fabs(f.lo[k]), b = std::fabs(f.hi[k]);
             if (!((a == 0.0 || (a >= 1e-100 && a <= 1e100)) && (b == 0.0 || (b >= 1e-100 && b <= 1e100)))) s->dev.regular = 0;
         }
-    for (int k = 0; k < 3; k++) s->dev.background[k] = d->background[k];
-    s->meshes = infos;
+    for (int k = 0; k < 3; k++) s->dev.background[k] = H.background[k];
+    s->meshes = H.infos;
     for (int k = 0; k < 2; k++) {
-        s->implicit_info[k] = implicit_info[k];
-        s->implicit_boxes[k].swap(implicit_boxes[k]);
-        s->has_implicit[k] = has_implicit[k];
+        s->implicit_info[k] = H.implicit_info[k];
+        s->implicit_boxes[k] = H.implicit_boxes[k];
+        s->has_implicit[k] = H.has_implicit[k];
     }
     s->materials = mats;
-    s->nlights = (int)d->nlights;
+    s->nlights = (int)H.nlights;
     s->dev.shade_kinds = 0;                           // over the materials that objects use
     for (const DevObject &q : objs) {
         const rt_material &m = mats[q.material];
@@ -563,6 +592,44 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
     *out = s;
     return 0;
 }
+
+int rt_scene_create(const rt_scene_desc *d, rt_scene **out)
+{
+    if (!d || !out) return fail("rt_scene_create: null argument");
+    *out = nullptr;
+    HostScene H;
+    if (int rc = assemble_scene(d, H)) return rc;
+    return upload_scene(H, out);
+}
+
+} // extern "C"
+
+int rt::create_scenes(const rt_scene_desc *d, const int *devices, int n, rt_scene **out)
+{
+    if (!d || !devices || n <= 0 || !out) return fail("create_scenes: bad argument");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    HostScene H;
+    if (int rc = assemble_scene(d, H)) return rc;
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; i++)
+        th.emplace_back([&, i]() {
+            hipError_t e = hipSetDevice(devices[i]);
+            rcs[i] = e == hipSuccess ? upload_scene(H, &out[i]) : fail_hip("hipSetDevice", e);
+            if (rcs[i]) errs[i] = g_err;            // the error text is per thread
+        });
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n; i++)
+        if (rcs[i]) {
+            for (int k = 0; k < n; k++) if (out[k]) { rt_scene_destroy(out[k]); out[k] = nullptr; }
+            g_err = errs[i];
+            return rcs[i];
+        }
+    return 0;
+}
+
+extern "C" {
 
 int rt_scene_octree_stats(const rt_scene *s, int mesh, uint64_t out[6])
 {

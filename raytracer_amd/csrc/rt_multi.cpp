@@ -242,12 +242,10 @@ int rt_multi_create(const rt_scene_desc *desc, const int *devices, int ndev, int
     if (reduce_mode != RT_REDUCE_RCCL && reduce_mode != RT_REDUCE_HOST) return rt::set_error("rt_multi_create: unknown reduce mode", -1);
     rt_multi *M = new rt_multi;
     M->m.resize(ndev);
-    int rc = 0;
-    for (int i = 0; i < ndev && rc == 0; i++) {
-        M->m[i].device = devices[i];
-        rc = rt_set_device(devices[i]);
-        if (rc == 0) rc = rt_scene_create(desc, &M->m[i].scene);
-    }
+    // the octrees are built once; every device then takes its copy of the scene, side by side
+    std::vector<rt_scene *> scenes(ndev, nullptr);
+    int rc = rt::create_scenes(desc, devices, ndev, scenes.data());
+    for (int i = 0; i < ndev; i++) { M->m[i].device = devices[i]; M->m[i].scene = scenes[i]; }
     if (rc == 0 && reduce_mode == RT_REDUCE_RCCL) rc = rt_comm_create(ndev, devices, &M->comm);
     if (rc) { const std::string keep = rt_last_error(); rt_multi_destroy(M); return rt::set_error(keep, rc); }
     *out = M;
