@@ -44,6 +44,25 @@ def test_virtual_members_on_one_card_add_up_to_the_single_device_frame():
     assert np.array_equal(bgr, hip.resolve_bgr8_host(img, 12, hip.TONE_SQRT))
 
 
+def test_members_share_one_octree_build():
+    """rt_multi_create builds the octrees once and hands every member its copy: four members cost about
+    what one scene costs (the build dominates), and all four hold the same trees."""
+    import time
+    desc, cam = scenes.atrium_scene(detail=0.6)
+    t0 = time.perf_counter()
+    one = hip.HipScene(desc)
+    t_one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ms = hip.MultiScene(desc, [0] * 4, hip.REDUCE_HOST)
+    t_four = time.perf_counter() - t0
+    assert t_four < 2.0 * t_one + 0.5, (t_one, t_four)
+    c, prm = hip.camera_init(**cam), render_params(64, 36, 2, 2, seed=9, max_jump=8)
+    img, _, k = ms.render(c, prm)
+    ref, kr = one.render(c, prm)
+    assert np.array_equal(k, kr) and np.allclose(img, ref, rtol=1e-12, atol=1e-14)
+    ms.close()
+
+
 def test_rccl_path_with_one_member():
     """RT_REDUCE_RCCL on the devices this machine has (one): the reduce runs through RCCL."""
     desc, c, prm = _frame()
