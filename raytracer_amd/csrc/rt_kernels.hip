@@ -1711,11 +1711,12 @@ struct StackSrc {
     {
         const uint64_t slot = base + i;
         const uint64_t meta = q.f[(uint64_t)RAY_META * q.cap + slot];
+        // origin and direction are asked for together with the depth word (one wait, not two)
+        e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
+        d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
         const int jump = (int)((meta >> 56) & 63);
         // depth cut-off (scene.cpp:196-198) happens before any intersection work
         if (jump + 1 > A.max_jump) return false;
-        e = mk(ray_f(q, slot, RAY_EX), ray_f(q, slot, RAY_EY), ray_f(q, slot, RAY_EZ));
-        d = mk(ray_f(q, slot, RAY_DX), ray_f(q, slot, RAY_DY), ray_f(q, slot, RAY_DZ));
         const bool first = jump == A.jumptime && ((meta >> 62) & 1);
         t0 = first ? A.t0 : RT_ZERO;
         t1 = first ? A.t1 : RT_INFINITE;
