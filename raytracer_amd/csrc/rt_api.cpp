@@ -428,7 +428,7 @@ static int assemble_scene(const rt_scene_desc *d, HostScene &H)
     // octree.cpp:61-99), so "the later of two equal hits" (octree.cpp:31) is the one with the larger index
     // and the kernels can settle ties by index whatever the order of the records.  The run of a mesh whose
     // whole octree is one leaf keeps its order: the object sweep walks it record by record.
-    leaf_box.assign((leaf_tris.size() + RT_SPH_SPARE) * 2, 0u);
+    leaf_box.assign((leaf_tris.size() + RT_BOX_SPARE) * 2, 0u);
     seg_box.assign((leaf_tris.size() / RT_SEG_RECS + nodes.size() + 2) * 2, 0u);
     run_box.assign(nodes.size() * 2 + 2, 0u);                     // per node: the union of its run's boxes
     for (size_t i = 0; i < leaf_box.size() / 2; i++) store_whole_node_box(&leaf_box[2 * i]);

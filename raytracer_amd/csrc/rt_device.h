@@ -8,13 +8,13 @@
 namespace rt {
 
 // Bounding boxes of the records of a node's run, for the kernels' single-precision pre-test.
-// They live in the node's own grid, one byte a coordinate: the node's box starts at RT_SPH_ORG on
-// every axis and its longest edge is RT_SPH_EDGE units, which leaves half an edge of room on either
+// They live in the node's own grid, one byte a coordinate: the node's box starts at RT_GRID_ORG on
+// every axis and its longest edge is RT_GRID_EDGE units, which leaves half an edge of room on either
 // side.  A box is two words, lo.x | lo.y << 8 | lo.z << 16 | hi.x << 24 , hi.y | hi.z << 8
 // (rt_pretest.h); two boxes to a 16-byte load.
-#define RT_SPH_EDGE 127u
-#define RT_SPH_ORG 64u
-#define RT_SPH_SPARE 64          // spare boxes after the last record: a chunk of 64 is read from any record on without clamping
+#define RT_GRID_EDGE 127u
+#define RT_GRID_ORG 64u
+#define RT_BOX_SPARE 64          // spare boxes after the last record: a chunk of 64 is read from any record on without clamping
 #ifndef RT_SEG_RECS
 #define RT_SEG_RECS 16
 #endif

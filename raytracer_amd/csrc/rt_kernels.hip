@@ -489,8 +489,8 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         // the ray for the box pre-test: the point g where it enters this node's box, in the node's grid, as
         // c = -g / direction per axis, and the length of its stretch inside the box (see RayB)
         const float sc = __uint_as_float(nd_pad & ~1u);
-        const float gx = (float)((e.x + d.x * n0) - lo0) * sc + (float)RT_SPH_ORG, gy = (float)((e.y + d.y * n0) - lo1) * sc + (float)RT_SPH_ORG;
-        const float gz = (float)((e.z + d.z * n0) - lo2) * sc + (float)RT_SPH_ORG;
+        const float gx = (float)((e.x + d.x * n0) - lo0) * sc + (float)RT_GRID_ORG, gy = (float)((e.y + d.y * n0) - lo1) * sc + (float)RT_GRID_ORG;
+        const float gz = (float)((e.z + d.z * n0) - lo2) * sc + (float)RT_GRID_ORG;
         const float4 fi = rayf[0][tid];
         const float dlen = rayf[1][tid].w;
         RayB rb;
@@ -525,7 +525,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
 //      left gets the round to itself, its segments named by all lanes at once.  Every lane then takes
 //      one listed segment, fetches the segment's box and its owner's ray and makes the box pre-test:
 //      segments that pass go to the wave's work table (ballot + count of the set bits below the
-//      lane), the others -- more than four in five in a typical scene -- are done with.  Rounds
+//      lane), the others are done with: none of their records is looked at.  Rounds
 //      repeat until the work table holds four chunks' worth or the owners have nothing left;
 //   2. pre-test: a chunk = 64 * RT_LANE_RECS / RT_SEG consecutive segments of the work table; every
 //      lane takes RT_LANE_RECS consecutive records of its segment, tests their boxes against the
@@ -535,12 +535,12 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
 //      and window (cross-lane reads) and makes the fp64 primitive test -- up to 64 candidates of
 //      different owners per pass;
 //   4. per owner the pass keeps the smallest hit distance (an LDS minimum over order-preserving
-//      integer keys) and, among the candidates that reached it, the last one in list order (an LDS
-//      maximum over list position | id): OctreeNode::hit accepts a hit with `t <= tempt`, so of equal
-//      distances the later primitive wins (octree.cpp:31), and a hit farther than an earlier one
-//      never survives -- the same outcome as testing the owner's candidates one after the other.
-//      (Candidates of one owner reach the list in run order: rounds, segments and chunks all go
-//      forward through the run.)
+//      integer keys) and, among the candidates that reached it, the one with the largest primitive
+//      index (an LDS maximum): OctreeNode::hit accepts a hit with `t <= tempt`, so of equal distances
+//      the primitive that comes later in the node's list wins (octree.cpp:31) -- the list is in index
+//      order, so that is the larger index, whatever order the records of the run are stored in -- and
+//      a hit farther than an earlier one never survives: the same outcome as testing the owner's
+//      candidates one after the other in list order.
 // The wave's cost follows the number of records near its rays, not its longest run, and the fp64
 // tests of all owners share their instructions.
 #ifndef RT_CAND_CAP
@@ -586,7 +586,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
                                           const float4 (*rayf)[BLOCK], CoopLds &L, Counters &c)
 {
     static_assert((RT_CAND_CAP & (RT_CAND_CAP - 1)) == 0 && RT_CAND_CAP >= 64, "candidate ring");
-    static_assert((RT_SEG & (RT_SEG - 1)) == 0 && RT_SEG <= 64 && RT_SEG <= RT_SPH_SPARE, "segment size");
+    static_assert((RT_SEG & (RT_SEG - 1)) == 0 && RT_SEG <= 64 && RT_SEG <= RT_BOX_SPARE, "segment size");
     // a chunk = RT_LANE_RECS consecutive records per lane, RT_SEG / RT_LANE_RECS lanes to a segment
     constexpr uint32_t LANES_PER_SEG = RT_SEG / RT_LANE_RECS, SEGS_PER_CHUNK = 64u / LANES_PER_SEG;
     static_assert(RT_LANE_RECS == 4 && RT_SEG % RT_LANE_RECS == 0, "a lane's boxes are two 16-byte loads");

@@ -18,7 +18,7 @@ struct FlatNode {
     uint32_t obj_begin;   // first record of this node's triangle run
     uint32_t obj_count;
     uint32_t pad;         // bit 0: the node's primitives are voxels of an implicit surface; bits 1-31, once the scene is
-                          // assembled: the float scale of the node's sphere grid (units per length, lowest bit cleared)
+                          // assembled: the float scale of the node's pre-test grid (units per length, lowest bit cleared)
 };
 static_assert(sizeof(FlatNode) == 64, "FlatNode must be 64 bytes");
 

@@ -23,13 +23,13 @@ inline float node_grid_scale(const FlatNode &n)
         if (e > ext) ext = e;
     }
     if (!(ext > 0)) return 0.0f;
-    const double sc = (double)RT_SPH_EDGE / ext;
+    const double sc = (double)RT_GRID_EDGE / ext;
     if (!(sc > 1e-30 && sc < 1e30)) return 0.0f;
     float f = (float)sc;
     uint32_t bits;
     std::memcpy(&bits, &f, 4);
     bits &= ~1u;                                      // rounds the scale down by at most one ulp: the box still fits
-    if ((double)f > sc) bits -= 2u;                   // never above RT_SPH_EDGE / ext
+    if ((double)f > sc) bits -= 2u;                   // never above RT_GRID_EDGE / ext
     std::memcpy(&f, &bits, 4);
     return f;
 }
@@ -37,8 +37,8 @@ inline float node_grid_scale(const FlatNode &n)
 // ---------------------------------------------------------------- pre-test boxes
 // The kernels' single-precision pre-test asks whether the ray crosses a box around the part of the
 // record's primitive that lies inside the node's box, within the node's window.  Boxes are stored
-// as bytes in the node's own grid (the node's box starts at RT_SPH_ORG on every axis, its longest
-// edge is RT_SPH_EDGE units): {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, 0, 0}, rounded outwards.
+// as bytes in the node's own grid (the node's box starts at RT_GRID_ORG on every axis, its longest
+// edge is RT_GRID_EDGE units): {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, 0, 0}, rounded outwards.
 // A primitive test only accepts a hit inside the node's window, the stretch of the ray inside the
 // node's box (octree.cpp:19-38 with the window of algorithms.h:223-236), so the part of a triangle
 // outside the box cannot be hit from this run.  The node's box is grown by 1/64 of its longest edge
@@ -110,7 +110,7 @@ inline BoxD clipped_voxel_box(const LeafTri &t, const FlatNode &n)
 // the whole grid (0 .. 255 on every axis): every ray that crosses the node passes.  A valid stand-in for
 // any record whose own box cannot be expressed: the primitive tests only accept hits inside the node's window.
 inline void store_whole_node_box(uint32_t *dst) { dst[0] = 0xFF000000u; dst[1] = 0x0000FFFFu; }
-// An empty box: the single grid point (0, 0, 0), at least RT_SPH_ORG - 3 units outside the node's grown box
+// An empty box: the single grid point (0, 0, 0), at least RT_GRID_ORG - 3 units outside the node's grown box
 // on every axis, so no ray reaches it inside the node's window.
 inline void store_empty_box(uint32_t *dst) { dst[0] = 0u; dst[1] = 0u; }
 // The box in the node's grid, rounded outwards: 2e-3 grid units beyond the bounds (the kernels'
@@ -129,7 +129,7 @@ inline void pack_box(uint32_t *dst, const BoxD &b, const FlatNode &n, float scal
     const double sc = (double)scale;
     uint32_t lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-        const double glo = (b.lo[k] - n.lo[k]) * sc + (double)RT_SPH_ORG, ghi = (b.hi[k] - n.lo[k]) * sc + (double)RT_SPH_ORG;
+        const double glo = (b.lo[k] - n.lo[k]) * sc + (double)RT_GRID_ORG, ghi = (b.hi[k] - n.lo[k]) * sc + (double)RT_GRID_ORG;
         if (!std::isfinite(glo) || !std::isfinite(ghi)) return;
         double l = std::floor(glo - 2e-3), h = std::ceil(ghi + 2e-3);
         if (l < 0) l = 0;

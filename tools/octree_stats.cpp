@@ -137,10 +137,10 @@ int main(int argc, char **argv)
                 p.empty = !clipped_box(lt, n, blo, bhi);
                 if (p.empty) for (int k = 0; k < 3; k++) { blo[k] = n.lo[k]; bhi[k] = n.lo[k]; }
                 for (int k = 0; k < 3; k++) {
-                    double glo = (blo[k] - n.lo[k]) * scale + RT_SPH_ORG, ghi = (bhi[k] - n.lo[k]) * scale + RT_SPH_ORG;
+                    double glo = (blo[k] - n.lo[k]) * scale + RT_GRID_ORG, ghi = (bhi[k] - n.lo[k]) * scale + RT_GRID_ORG;
                     double flo = std::floor(glo - 2e-3), fhi = std::ceil(ghi + 2e-3);
-                    p.qlo[k] = (flo - RT_SPH_ORG) / scale + n.lo[k];
-                    p.qhi[k] = (fhi - RT_SPH_ORG) / scale + n.lo[k];
+                    p.qlo[k] = (flo - RT_GRID_ORG) / scale + n.lo[k];
+                    p.qhi[k] = (fhi - RT_GRID_ORG) / scale + n.lo[k];
                 }
             }
         }
@@ -151,7 +151,7 @@ int main(int argc, char **argv)
             for (uint32_t i = 0; i < n.obj_count; i++) {
                 const Pre &p = T.pre[n.obj_begin + i];
                 uint32_t c[3];
-                for (int k = 0; k < 3; k++) c[k] = (uint32_t)std::min(255.0, std::max(0.0, ((p.qlo[k] + p.qhi[k]) / 2 - n.lo[k]) * scale + RT_SPH_ORG));
+                for (int k = 0; k < 3; k++) c[k] = (uint32_t)std::min(255.0, std::max(0.0, ((p.qlo[k] + p.qhi[k]) / 2 - n.lo[k]) * scale + RT_GRID_ORG));
                 key[i] = {p.empty ? 0xFFFFFFFFu : morton3(c[0], c[1], c[2]), n.obj_begin + i};
             }
             std::sort(key.begin(), key.end());
