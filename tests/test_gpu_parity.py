@@ -525,6 +525,18 @@ def test_profile_counters_are_consistent():
     # every round traces and shades one chunk of bounce rays; shadow-ray launches come on top
     assert p["shade_launches"] >= 1 and p["trace_ms"] > 0 and p["trace_launches"] >= p["shade_launches"]
     assert int(cnt[0]) > 64 * 64 * 4
+    # the per-stage counters add up to the call's own four, launch for launch and ray for ray; the
+    # engine stages made box tests and fewer fp64 tests than the primitives their walks covered
+    ks = sg.get_kernel_stats()
+    for j, name in enumerate(("rays", "inner", "leaf", "prim")):
+        assert sum(int(v[name]) for v in ks.values()) == int(cnt[j])
+    assert sum(v["launches"] for v in ks.values()) == p["trace_launches"]
+    assert abs(sum(v["ms"] for v in ks.values()) - p["trace_ms"]) < 1e-6 * max(1.0, p["trace_ms"])
+    eng = ks["k_trace"]
+    assert eng["box_tests"] > 0 and 0 < eng["fp64_tests"] < eng["prim"]
+    sw = ks["k_sweep+k_trace_retry"]
+    assert sw["rays"] > 0 and sw["box_tests"] == 0 and sw["fp64_tests"] == sw["prim"]    # the walls' lists are walked whole
+    assert all(v["launches"] == 0 and v["rays"] == 0 for v in sg.get_kernel_stats().values())   # reading reset them
 
 
 def test_cpp_scene_api_example_matches_oracle(tmp_path):
