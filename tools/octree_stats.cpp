@@ -52,7 +52,7 @@ static bool tri_hit(const LeafTri &tr, V e, V d, double t0, double t1, double &t
     return true;
 }
 
-// the clipped polygon's bounds (same clip as clipped_triangle_sphere); false if nothing is left
+// the bounds of the triangle clipped to the grown node box (as clipped_triangle_box in rt_pretest.h); false if nothing is left
 static bool clipped_box(const LeafTri &t, const FlatNode &n, double lo[3], double hi[3])
 {
     double ext = 0;
