@@ -433,52 +433,91 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         const double am0 = qdiv<FAST>((lo0 + hi0) / 2 - e.x, d.x, r.x);
         const double am1 = qdiv<FAST>((lo1 + hi1) / 2 - e.y, d.y, r.y);
         const double am2 = qdiv<FAST>((lo2 + hi2) / 2 - e.z, d.z, r.z);
-        const double mnL[3] = { tmin2<FAST>(al0, am0), tmin2<FAST>(al1, am1), tmin2<FAST>(al2, am2) };
-        const double mxL[3] = { tmax2<FAST>(al0, am0), tmax2<FAST>(al1, am1), tmax2<FAST>(al2, am2) };
-        const double mnH[3] = { tmin2<FAST>(am0, ah0), tmin2<FAST>(am1, ah1), tmin2<FAST>(am2, ah2) };
-        const double mxH[3] = { tmax2<FAST>(am0, ah0), tmax2<FAST>(am1, ah1), tmax2<FAST>(am2, ah2) };
-        // entry distance per child, +inf for children the ray misses
-        double ct[8];
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int ci = 0; ci < 8; ci++) {
-            // corner order of getChildBound: x-half, y-half, z-half of child ci
-            const int hx = (ci == 1 || ci == 2 || ci == 5 || ci == 6), hy = (ci == 2 || ci == 3 || ci == 6 || ci == 7), hz = ci >> 2;
-            double r0, r1;
-            if (FAST) {
-                r0 = fmax(fmax(hx ? mnH[0] : mnL[0], hy ? mnH[1] : mnL[1]), fmax(hz ? mnH[2] : mnL[2], t0));
-                r1 = fmin(fmin(hx ? mxH[0] : mxL[0], hy ? mxH[1] : mxL[1]), fmin(hz ? mxH[2] : mxL[2], t1));
-            } else {
-                double q;
-                r0 = hx ? mnH[0] : mnL[0]; r1 = hx ? mxH[0] : mxL[0];
-                q = hy ? mnH[1] : mnL[1]; if (r0 < q) r0 = q;
-                q = hz ? mnH[2] : mnL[2]; if (r0 < q) r0 = q;
-                if (r0 < t0) r0 = t0;
-                q = hy ? mxH[1] : mxL[1]; if (q < r1) r1 = q;
-                q = hz ? mxH[2] : mxL[2]; if (q < r1) r1 = q;
-                if (t1 < r1) r1 = t1;
-            }
-            const bool h = r0 <= r1;
-            ct[ci] = h ? r0 : __builtin_huge_val();
-            cnt += h ? 1u : 0u;
-        }
-        // std::sort by entry distance (octree.cpp:344); equal keys keep child order.  rank[i] is
-        // child i's place in that order: i, plus later children that go first (strictly smaller
-        // key), minus earlier children it overtakes.  The hit children take ranks 0..cnt-1.
-        // Child 0 contributes nothing to the packed order word, so its rank is not formed.
-        uint32_t rank[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-#pragma unroll
-            for (int j = i + 1; j < 8; j++) {
-                const uint32_t jfirst = ct[j] < ct[i] ? 1u : 0u;
-                if (i) rank[i] += jfirst;
-                rank[j] -= jfirst;
+        uint32_t cnt = 0, order = 0;
+        // The children the ray passes through and their order, the short way: in exact arithmetic the
+        // outcome of the eight slab tests and the sort below is a function of the ORDER of the numbers
+        // they compare -- the nine plane distances and the window's ends, no new arithmetic -- and
+        // while no two of the numbers that matter are equal it is this: the ray enters the node at n0 in
+        // the octant that axis k puts it in (the near half unless the middle plane lies behind the entry,
+        // am_k < n0), and every middle plane it crosses inside the window, n0 < am_k < n1, takes it to
+        // the next octant, in the order of the am_k; each octant is entered where the one before is
+        // left, so the entry distances increase strictly and no tie rule comes into play.  Equal numbers
+        // (a middle plane met exactly at the window's end, two middle planes met together) mean children
+        // touched in a single point, which the reference visits and orders by index: then the whole
+        // wave takes the long way below, literally.  (Checked against it for every order of the values.)
+        bool long_way = true;
+        if (FAST) {
+            const bool g0 = am0 > n0, g1 = am1 > n0, g2 = am2 > n0;
+            const bool i0 = g0 & (am0 < n1), i1 = g1 & (am1 < n1), i2 = g2 & (am2 < n1);
+            const bool tie = (am0 == n0) | (am1 == n0) | (am2 == n0) | (am0 == n1) | (am1 == n1) | (am2 == n1) |
+                             (i0 & i1 & (am0 == am1)) | (i0 & i2 & (am0 == am2)) | (i1 & i2 & (am1 == am2));
+            long_way = __any(tie);
+#if RT_STEP_STATS == 12
+            c.rays++; if (long_way) c.inner++; if (tie) c.leaf++;      // lanes at inner nodes, lanes taken the long way, lanes with a tie of their own
+#endif
+            if (!long_way) {
+                const bool y_lt_x = am1 < am0, z_lt_x = am2 < am0, z_lt_y = am2 < am1;
+                // crossings that come before this axis's own
+                const bool ax = i1 & y_lt_x, bx = i2 & z_lt_x, ay = i0 & !y_lt_x, by = i2 & z_lt_y, az = i0 & !z_lt_x, bz = i1 & !z_lt_y;
+                // the half (0 low, 1 high) per axis in the first octant, and which axes have flipped by the second, third, fourth
+                const uint32_t o0 = (uint32_t)((d.x < 0) != !g0) | (uint32_t)((d.y < 0) != !g1) << 1 | (uint32_t)((d.z < 0) != !g2) << 2;
+                const uint32_t f1 = (uint32_t)(i0 & !ax & !bx) | (uint32_t)(i1 & !ay & !by) << 1 | (uint32_t)(i2 & !az & !bz) << 2;
+                const uint32_t f2 = (uint32_t)(i0 & !(ax & bx)) | (uint32_t)(i1 & !(ay & by)) << 1 | (uint32_t)(i2 & !(az & bz)) << 2;
+                const uint32_t f3 = (uint32_t)i0 | (uint32_t)i1 << 1 | (uint32_t)i2 << 2;
+                cnt = 1u + (uint32_t)i0 + (uint32_t)i1 + (uint32_t)i2;
+                // x-half | y-half << 1 | z-half << 2  ->  child index in getChildBound's corner order (0 1 3 2 4 5 7 6)
+                auto kid = [](uint32_t oct) { return (0xDEC4C8u >> (3u * oct)) & 7u; };
+                order = kid(o0) | kid(o0 ^ f1) << 3 | kid(o0 ^ f2) << 6 | kid(o0 ^ f3) << 9;
             }
         }
-        uint32_t order = 0;
-#pragma unroll
-        for (int i = 1; i < 8; i++) order |= (uint32_t)i << (3 * rank[i]);
+        if (long_way) {
+            const double mnL[3] = { tmin2<FAST>(al0, am0), tmin2<FAST>(al1, am1), tmin2<FAST>(al2, am2) };
+            const double mxL[3] = { tmax2<FAST>(al0, am0), tmax2<FAST>(al1, am1), tmax2<FAST>(al2, am2) };
+            const double mnH[3] = { tmin2<FAST>(am0, ah0), tmin2<FAST>(am1, ah1), tmin2<FAST>(am2, ah2) };
+            const double mxH[3] = { tmax2<FAST>(am0, ah0), tmax2<FAST>(am1, ah1), tmax2<FAST>(am2, ah2) };
+            // entry distance per child, +inf for children the ray misses
+            double ct[8];
+            cnt = 0;
+    #pragma unroll
+            for (int ci = 0; ci < 8; ci++) {
+                // corner order of getChildBound: x-half, y-half, z-half of child ci
+                const int hx = (ci == 1 || ci == 2 || ci == 5 || ci == 6), hy = (ci == 2 || ci == 3 || ci == 6 || ci == 7), hz = ci >> 2;
+                double r0, r1;
+                if (FAST) {
+                    r0 = fmax(fmax(hx ? mnH[0] : mnL[0], hy ? mnH[1] : mnL[1]), fmax(hz ? mnH[2] : mnL[2], t0));
+                    r1 = fmin(fmin(hx ? mxH[0] : mxL[0], hy ? mxH[1] : mxL[1]), fmin(hz ? mxH[2] : mxL[2], t1));
+                } else {
+                    double q;
+                    r0 = hx ? mnH[0] : mnL[0]; r1 = hx ? mxH[0] : mxL[0];
+                    q = hy ? mnH[1] : mnL[1]; if (r0 < q) r0 = q;
+                    q = hz ? mnH[2] : mnL[2]; if (r0 < q) r0 = q;
+                    if (r0 < t0) r0 = t0;
+                    q = hy ? mxH[1] : mxL[1]; if (q < r1) r1 = q;
+                    q = hz ? mxH[2] : mxL[2]; if (q < r1) r1 = q;
+                    if (t1 < r1) r1 = t1;
+                }
+                const bool h = r0 <= r1;
+                ct[ci] = h ? r0 : __builtin_huge_val();
+                cnt += h ? 1u : 0u;
+            }
+            // std::sort by entry distance (octree.cpp:344); equal keys keep child order.  rank[i] is
+            // child i's place in that order: i, plus later children that go first (strictly smaller
+            // key), minus earlier children it overtakes.  The hit children take ranks 0..cnt-1.
+            // Child 0 contributes nothing to the packed order word, so its rank is not formed.
+            uint32_t rank[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+    #pragma unroll
+            for (int i = 0; i < 8; i++) {
+    #pragma unroll
+                for (int j = i + 1; j < 8; j++) {
+                    const uint32_t jfirst = ct[j] < ct[i] ? 1u : 0u;
+                    if (i) rank[i] += jfirst;
+                    rank[j] -= jfirst;
+                }
+            }
+            order = 0;
+    #pragma unroll
+            for (int i = 1; i < 8; i++) order |= (uint32_t)i << (3 * rank[i]);
+        }
         if (cnt) {
             stk[0][T.sp][tid] = child_base;
             stk[1][T.sp][tid] = order | (cnt << 24);
@@ -887,7 +926,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
     if (lane == 0) { c.box += nbox; c.fp64 += tested; }
 #endif
     if (owner) {
-#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9 && RT_STEP_STATS != 10
+#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9 && RT_STEP_STATS != 10 && RT_STEP_STATS != 12
         c.prim += T.kend - T.k;
 #endif
         bool improved = false;
