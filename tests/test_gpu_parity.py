@@ -106,6 +106,35 @@ def test_group_hit_matches_reference_golden(golden_dir):
     assert np.array_equal(t[hit], g["t"][hit]) and np.array_equal(nrm[hit], g["normal"][hit])
 
 
+def test_rays_that_meet_splitting_planes_exactly():
+    """A node step finds the children a ray passes through from the order of the plane distances, and
+    falls back to the reference's eight slab tests and its sort when two of the numbers that matter are
+    equal (a middle plane met exactly at the window's end, two middle planes met together): rays that
+    start on splitting planes with t0 = 0, rays through node centres and along node diagonals give such
+    ties; ids, distances, normals and all four work counters must stay the oracle's."""
+    rng = np.random.default_rng(23)
+    tris = np.clip(scenes.soup(20000, seed=97, edge_lo=4e-3, edge_hi=4e-2), 0.0, 1.0)
+    corners = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0], [1, 1, 1, 0, 1, 1, 1, 0, 1]], float)      # the mesh's bounds are the unit cube: splits at k / 2^d
+    desc = _mesh_desc(np.ascontiguousarray(np.concatenate([corners, tris])), octree_max_size=32, octree_max_depth=12)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    n = 24000
+    rays = np.zeros(n, RAY_DT)
+    e = rng.integers(1, 32, (n, 3)) / 32.0                     # origins on splitting planes of every depth down to 5
+    e[: n // 4] += rng.uniform(-0.3, 0.3, (n // 4, 3)) * (rng.random((n // 4, 3)) < 0.5)   # some coordinates off the planes
+    target = rng.integers(0, 17, (n, 3)) / 16.0                # through node corners and centres
+    target[n // 2:] = rng.uniform(0, 1, (n - n // 2, 3))
+    d = target - e
+    d[np.abs(d).sum(axis=1) == 0] = (1.0, 1.0, 1.0)
+    diag = rng.random(n) < 0.2
+    d[diag] = np.sign(d[diag] + 1e-30) * np.abs(d[diag]).max(axis=1, keepdims=True)        # exact diagonals: two or three middle planes met together
+    rays["e"], rays["d"] = e, d
+    for t0, t1 in ((0.0, 1e10), (0.0, 0.5), (0.25, 1.0)):
+        p1, d1, n1, c1 = so.trace_rays(rays, t0, t1)
+        p2, d2, n2, c2 = sg.trace_rays(rays, t0, t1)
+        assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
+    assert (p1 != MISS).mean() > 0.2
+
+
 def test_reference_edge_branches_on_device(golden_dir):
     """The constructed edge cases of the golden vectors through the kernels: tangent rays, whose hit is
     reported whatever the window (Surface.cpp:79-81), and rays that start on a plane
