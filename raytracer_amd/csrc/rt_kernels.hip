@@ -390,7 +390,7 @@ __device__ __forceinline__ TriReg tri_load_uniform(u_leaftri p)
 
 template <bool FAST, int BLOCK>
 __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode,
-                                          uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], double *run_bt1, float4 (*rayf)[BLOCK], Counters &c)
+                                          uint2 (*stk)[BLOCK], double *run_bt1, float4 (*rayf)[BLOCK], Counters &c)
 {
     const int tid = threadIdx.x;
     const V3 e = T.e, d = T.d, r = T.r;
@@ -401,6 +401,16 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count, nd_pad = nd->pad;
     uint2 run_box;                                          // around everything in the node's run (asked for together with the node)
     __builtin_memcpy(&run_box, S.run_box + 2ull * T.cur, 8);
+#if RT_STEP_STATS == 13
+    // clock ticks (/16), lane 0 of the wave's active lanes: inner = the wait for the node record, leaf = the rest of the step
+    const bool first_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;
+    const long long tn0_ = clock64();
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lo0 + hi0 + (double)child_base + (double)run_box.x == 1.2345e300) c.prim++;
+    const long long tn1_ = clock64();
+    if (first_) c.inner += (uint32_t)((tn1_ - tn0_) >> 4);
+    struct Tock { long long t; bool f; Counters &c; __device__ ~Tock() { if (f) c.leaf += (uint32_t)((clock64() - t) >> 4); } } tock_{tn1_, first_, c};
+#endif
     // per-axis plane distances; the node's own slab test and all 8 child tests use them
     const double al0 = qdiv<FAST>(lo0 - e.x, d.x, r.x), al1 = qdiv<FAST>(lo1 - e.y, d.y, r.y), al2 = qdiv<FAST>(lo2 - e.z, d.z, r.z);
     const double ah0 = qdiv<FAST>(hi0 - e.x, d.x, r.x), ah1 = qdiv<FAST>(hi1 - e.y, d.y, r.y), ah2 = qdiv<FAST>(hi2 - e.z, d.z, r.z);
@@ -519,8 +529,7 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
             for (int i = 1; i < 8; i++) order |= (uint32_t)i << (3 * rank[i]);
         }
         if (cnt) {
-            stk[0][T.sp][tid] = child_base;
-            stk[1][T.sp][tid] = order | (cnt << 24);
+            stk[T.sp][tid] = make_uint2(child_base, order | (cnt << 24));
             T.sp++;
         }
     }
@@ -926,7 +935,7 @@ __device__ __forceinline__ void tri_phase(const DevScene &S, TravState &T, int &
     if (lane == 0) { c.box += nbox; c.fp64 += tested; }
 #endif
     if (owner) {
-#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9 && RT_STEP_STATS != 10 && RT_STEP_STATS != 12
+#if RT_STEP_STATS != 1 && RT_STEP_STATS != 3 && RT_STEP_STATS != 4 && RT_STEP_STATS != 6 && RT_STEP_STATS != 7 && RT_STEP_STATS != 8 && RT_STEP_STATS != 9 && RT_STEP_STATS != 10 && RT_STEP_STATS != 12 && RT_STEP_STATS != 13
         c.prim += T.kend - T.k;
 #endif
         bool improved = false;
@@ -956,7 +965,7 @@ __device__ __forceinline__ void tri_test(const TriReg &tr, TravState &T)
 // octrees in a row); it never changes a result, and kernels compiled without it are leaner.
 template <int BLOCK, bool CHAIN = false, class Src>
 __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t *next, uint32_t batch_max,
-                                    uint32_t (*stk)[RT_STACK_LEVELS][BLOCK], Counters &c)
+                                    uint2 (*stk)[BLOCK], Counters &c)
 {
     const int tid = threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -987,22 +996,26 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
     long long tk0 = clock64();
     const long long tk_start = tk0;
 #define RT_TICK(field) { const long long tk1 = clock64(); if (lane == 0) c.field += (uint32_t)((tk1 - tk0) >> 4); tk0 = tk1; }
+#elif RT_STEP_STATS == 13
+    // rays = whole node steps (vote and pop included); node_step itself adds the wait for the node record and the rest
+    long long tk0 = clock64();
+#define RT_TICK(field) { const long long tk1 = clock64(); if (lane == 0 && #field[0] == 'i') c.rays += (uint32_t)((tk1 - tk0) >> 4); tk0 = tk1; }
 #else
 #define RT_TICK(field)
 #endif
     // The next node of the lane's depth-first walk: the next child, in sorted order, of the deepest
     // open node that has one left (octree.cpp:349-368); with none left the octree is finished.
     auto pop_now = [&]() {
-        mode = TM_OBJ;
-        while (T.sp > 0) {
-            const uint32_t w = stk[1][T.sp - 1][tid];
-            const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
-            if (pos == cnt) { T.sp--; continue; }
-            stk[1][T.sp - 1][tid] = w + (1u << 28);
-            T.cur = stk[0][T.sp - 1][tid] + ((w >> (3 * pos)) & 7u);
-            mode = TM_NODE;
-            break;
-        }
+        // a level leaves the stack together with its last child, so the top level always has a child
+        // left: one LDS read per pop, no unwinding through exhausted levels
+        if (T.sp == 0) { mode = TM_OBJ; return; }
+        const uint2 top = stk[T.sp - 1][tid];                      // {first child, order word}
+        const uint32_t w = top.y;
+        const uint32_t cnt = (w >> 24) & 15u, pos = w >> 28;
+        T.cur = top.x + ((w >> (3 * pos)) & 7u);
+        if (pos + 1u == cnt) T.sp--;
+        else stk[T.sp - 1][tid].y = w + (1u << 28);
+        mode = TM_NODE;
     };
     // A lane whose octree is finished and whose next object is an octree with inner nodes as well goes
     // straight on to that octree's root, without waiting for an object phase: Octree::hit's verdict
@@ -1433,7 +1446,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_ray_normals(DevScene S, const rt_r
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_rays(RaySrc src, uint32_t *next, uint64_t *counters)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    __shared__ uint2 stk[RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(src.S, src, next, 128u, stk, c);
     flush_counters(counters, nullptr, c);
@@ -1464,7 +1477,7 @@ struct PrimarySrc {         // rt_trace_primary: one ray through every pixel cen
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_primary(PrimarySrc src, uint32_t *next, uint64_t *counters)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    __shared__ uint2 stk[RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(src.S, src, next, 128u, stk, c);
     flush_counters(counters, nullptr, c);
@@ -1736,7 +1749,7 @@ template <bool CHAIN>
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow(DevScene S, ShadowSrc src, uint32_t *next, uint32_t batch_max, uint64_t *counters, uint64_t *kstats)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    __shared__ uint2 stk[RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK, CHAIN>(S, src, next, batch_max, stk, c);
     flush_counters(counters, kstats, c);
@@ -1779,7 +1792,7 @@ template <bool CHAIN>
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, StackSrc src, uint32_t *next, uint32_t batch_max)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    __shared__ uint2 stk[RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK, CHAIN>(S, src, next, batch_max, stk, c);
     flush_counters(src.A.counters, src.A.kstats ? src.A.kstats + RT_KSTAT_WORDS * RT_KSTAT_ENGINE : nullptr, c);
@@ -1902,7 +1915,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_sweep_shadow(DevScene S, ShadowSrc
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_retry(DevScene S, RetrySrc<StackSrc> src, uint32_t *next, uint32_t batch_max)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    __shared__ uint2 stk[RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
     flush_counters(src.b.A.counters, src.b.A.kstats ? src.b.A.kstats + RT_KSTAT_WORDS * RT_KSTAT_SWEEP : nullptr, c);
@@ -1910,7 +1923,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_retry(DevScene S, RetrySrc<S
 RT_TRACE_ATTR
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_shadow_retry(DevScene S, RetrySrc<ShadowSrc> src, uint32_t *next, uint32_t batch_max, uint64_t *counters, uint64_t *kstats)
 {
-    __shared__ uint32_t stk[2][RT_STACK_LEVELS][RT_BLOCK];
+    __shared__ uint2 stk[RT_STACK_LEVELS][RT_BLOCK];
     Counters c = { 0, 0, 0, 0, 0, 0 };
     trace_engine<RT_BLOCK>(S, src, next, batch_max, stk, c);
     flush_counters(counters, kstats, c);
