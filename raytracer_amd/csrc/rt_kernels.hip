@@ -388,25 +388,40 @@ __device__ __forceinline__ TriReg tri_load_uniform(u_leaftri p)
     return r;
 }
 
+__device__ __forceinline__ double any_f64() { double x; asm volatile("" : "=v"(x)); return x; }
+__device__ __forceinline__ uint32_t any_u32() { uint32_t x; asm volatile("" : "=v"(x)); return x; }
+
+// One step of the walk for every lane that stands at a node (`in`): the node's slab test, Octree::hit's
+// stop rule, the children the ray passes through pushed in order, and the node's own run opened if the
+// box around it lets the ray through.  Written without branches on per-lane conditions: an instruction
+// costs the wave the same whether one lane or all of them need it, and every join of divergent paths
+// costs register copies, so the lanes' outcomes are selected at the end instead; the only branches are
+// on conditions the whole wave shares.
 template <bool FAST, int BLOCK>
-__device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode,
+__device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &mode, const bool in,
                                           uint2 (*stk)[BLOCK], double *run_bt1, float4 (*rayf)[BLOCK], Counters &c)
 {
     const int tid = threadIdx.x;
     const V3 e = T.e, d = T.d, r = T.r;
     const double t0 = T.t0, t1 = T.t1;
-    const FlatNode *nd = S.nodes + T.cur;
-    const double lo0 = nd->lo[0], lo1 = nd->lo[1], lo2 = nd->lo[2];
-    const double hi0 = nd->hi[0], hi1 = nd->hi[1], hi2 = nd->hi[2];
-    const uint32_t child_base = nd->child_base, obj_begin = nd->obj_begin, obj_count = nd->obj_count, nd_pad = nd->pad;
-    uint2 run_box;                                          // around everything in the node's run (asked for together with the node)
-    __builtin_memcpy(&run_box, S.run_box + 2ull * T.cur, 8);
+    // lanes that take no part compute on whatever their registers hold (a value the compiler must treat
+    // as defined, made by no instruction): every result of theirs is masked by `in`
+    double lo0 = any_f64(), lo1 = any_f64(), lo2 = any_f64(), hi0 = any_f64(), hi1 = any_f64(), hi2 = any_f64();
+    uint32_t child_base = any_u32(), obj_begin = any_u32(), obj_count = any_u32(), nd_pad = any_u32();
+    uint2 run_box = make_uint2(any_u32(), any_u32());       // around everything in the node's run (asked for together with the node)
+    if (in) {
+        const FlatNode *nd = S.nodes + T.cur;
+        lo0 = nd->lo[0]; lo1 = nd->lo[1]; lo2 = nd->lo[2];
+        hi0 = nd->hi[0]; hi1 = nd->hi[1]; hi2 = nd->hi[2];
+        child_base = nd->child_base; obj_begin = nd->obj_begin; obj_count = nd->obj_count; nd_pad = nd->pad;
+        __builtin_memcpy(&run_box, S.run_box + 2ull * T.cur, 8);
+    }
 #if RT_STEP_STATS == 13
-    // clock ticks (/16), lane 0 of the wave's active lanes: inner = the wait for the node record, leaf = the rest of the step
+    // clock ticks (/16), lane 0 of the wave: inner = the wait for the node record, leaf = the rest of the step
     const bool first_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;
     const long long tn0_ = clock64();
     __builtin_amdgcn_s_waitcnt(0);
-    if (lo0 + hi0 + (double)child_base + (double)run_box.x == 1.2345e300) c.prim++;
+    if (lo0 + hi0 + (double)child_base + (double)run_box.x == 1.2345e300) c.box++;
     const long long tn1_ = clock64();
     if (first_) c.inner += (uint32_t)((tn1_ - tn0_) >> 4);
     struct Tock { long long t; bool f; Counters &c; __device__ ~Tock() { if (f) c.leaf += (uint32_t)((clock64() - t) >> 4); } } tock_{tn1_, first_, c};
@@ -428,17 +443,16 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         if (t1 < n1) n1 = t1;
     }
     const bool hb = n0 <= n1;
-    mode = TM_POP;
-    if (T.cur == T.root ? !hb : (T.mint < n0)) {           // octree.cpp:291 / octree.cpp:359-361
-        mode = TM_OBJ;                                     // this octree is finished
-        return;
-    }
+    // octree.cpp:291 / octree.cpp:359-361: a root the ray misses, or a node that starts behind the
+    // closest hit so far, finishes this octree
+    const bool alive = in & !(T.cur == T.root ? !hb : (T.mint < n0));
+    const bool inner = alive & (child_base != 0);
 #if !defined(RT_STEP_STATS)
-    if (child_base) c.inner++; else c.leaf++;
+    c.inner += inner ? 1u : 0u; c.leaf += (alive & !inner) ? 1u : 0u;
 #else
-    if (RT_STEP_STATS == 2 && !child_base) c.leaf++;
+    if (RT_STEP_STATS == 2) c.leaf += (alive & !inner) ? 1u : 0u;
 #endif
-    if (child_base) {
+    if (__any(inner)) {
         // 8 child slab tests (octree.cpp:337-343) from the {lo, mid, hi} plane distances
         const double am0 = qdiv<FAST>((lo0 + hi0) / 2 - e.x, d.x, r.x);
         const double am1 = qdiv<FAST>((lo1 + hi1) / 2 - e.y, d.y, r.y);
@@ -461,9 +475,9 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
             const bool i0 = g0 & (am0 < n1), i1 = g1 & (am1 < n1), i2 = g2 & (am2 < n1);
             const bool tie = (am0 == n0) | (am1 == n0) | (am2 == n0) | (am0 == n1) | (am1 == n1) | (am2 == n1) |
                              (i0 & i1 & (am0 == am1)) | (i0 & i2 & (am0 == am2)) | (i1 & i2 & (am1 == am2));
-            long_way = __any(tie);
+            long_way = __any(inner & tie);
 #if RT_STEP_STATS == 12
-            c.rays++; if (long_way) c.inner++; if (tie) c.leaf++;      // lanes at inner nodes, lanes taken the long way, lanes with a tie of their own
+            if (inner) { c.rays++; if (long_way) c.inner++; if (tie) c.leaf++; }    // lanes at inner nodes, lanes taken the long way, lanes with a tie of their own
 #endif
             if (!long_way) {
                 const bool y_lt_x = am1 < am0, z_lt_x = am2 < am0, z_lt_y = am2 < am1;
@@ -528,12 +542,13 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
     #pragma unroll
             for (int i = 1; i < 8; i++) order |= (uint32_t)i << (3 * rank[i]);
         }
-        if (cnt) {
-            stk[T.sp][tid] = make_uint2(child_base, order | (cnt << 24));
-            T.sp++;
-        }
+        const bool push = inner & (cnt != 0u);
+        if (push) stk[T.sp][tid] = make_uint2(child_base, order | (cnt << 24));
+        T.sp += push ? 1 : 0;
     }
-    if (hb && obj_count) {                                  // OctreeNode::hit, octree.cpp:19-38
+    const bool has = alive & hb & (obj_count != 0u);        // OctreeNode::hit, octree.cpp:19-38
+    bool open = false;
+    if (__any(has)) {
         // the ray for the box pre-test: the point g where it enters this node's box, in the node's grid, as
         // c = -g / direction per axis, and the length of its stretch inside the box (see RayB)
         const float sc = __uint_as_float(nd_pad & ~1u);
@@ -545,23 +560,22 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         rb.ix = fi.x; rb.iy = fi.y; rb.iz = fi.z;
         rb.cx = -(gx * fi.x); rb.cy = -(gy * fi.y); rb.cz = -(gz * fi.z);
         rb.tend = (float)(n1 - n0) * dlen * sc + RT_BOX_SLACK;
-        c.box++;
-        if (!box_pass(run_box.x, run_box.y, rb)) {
-            // the ray passes everything in this run at a distance: the run is covered without a look at
-            // its records (mode stays TM_POP: nothing was hit here)
+        // a run whose box the ray passes at a distance is covered without a look at its records
+        open = has & box_pass(run_box.x, run_box.y, rb);
+        c.box += has ? 1u : 0u;
 #if !defined(RT_STEP_STATS)
-            c.prim += obj_count;
+        c.prim += (has & !open) ? obj_count : 0u;
 #endif
-            return;
+        T.k = open ? obj_begin : T.k; T.kend = open ? obj_begin + obj_count : T.kend;
+        T.bt0 = open ? n0 : T.bt0; T.tempt = open ? n1 : T.tempt; T.bprim = open ? RT_MISS : T.bprim;
+        T.leaf = open ? child_base == 0 : T.leaf;
+        if (open) {
+            if (nd_pad & 1u) run_bt1[tid] = n1;             // voxel records read it back
+            rayf[1][tid] = make_float4(rb.cx, rb.cy, rb.cz, dlen);
+            rayf[0][tid].w = rb.tend;
         }
-        mode = TM_TRI;
-        T.k = obj_begin; T.kend = obj_begin + obj_count;
-        T.bt0 = n0; T.tempt = n1; T.bprim = RT_MISS;
-        T.leaf = child_base == 0;
-        if (nd_pad & 1u) run_bt1[tid] = n1;                 // voxel records read it back
-        rayf[1][tid] = make_float4(rb.cx, rb.cy, rb.cz, dlen);
-        rayf[0][tid].w = rb.tend;
     }
+    mode = !in ? mode : !alive ? TM_OBJ : open ? TM_TRI : TM_POP;
 }
 
 // ------------------------------------------------------------------ the cooperative triangle phase
@@ -1210,8 +1224,11 @@ __device__ inline void trace_engine(const DevScene &S, const Src &src, uint32_t 
 #endif
                 if (mode == TM_POP) pop_now();
                 const bool in = mode == TM_NODE;
-                if (__all(!in || T.fast)) { if (in) node_step<true, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
-                else { if (in) node_step<false, BLOCK>(S, T, mode, stk, run_bt1, rayf, c); }
+#if RT_STEP_STATS == 13
+                { const long long tv_ = clock64(); if (lane == 0) c.prim += (uint32_t)((tv_ - tk0) >> 4); }   // prim = the vote and the pop
+#endif
+                if (__all(!in || T.fast)) node_step<true, BLOCK>(S, T, mode, in, stk, run_bt1, rayf, c);
+                else node_step<false, BLOCK>(S, T, mode, in, stk, run_bt1, rayf, c);
                 if (CHAIN && ((mN >> lane) & 1ull) && mode == TM_OBJ) chain();
                 RT_TICK(inner)
                 continue;
