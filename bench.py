@@ -315,6 +315,8 @@ def main():
                     "executed_box_tests_per_ray": st["box_tests"] / rays,
                     "hw_valu_issue_share": issue, "hw_active_lanes_per_valu_inst": lanes,
                     "hw_valu_lane_util": issue * lanes / 64.0 if issue is not None and lanes is not None else None,
+                    "hw_lanes_note": "lanes enabled by EXEC, not lanes whose results are kept: the engine's node step runs without "
+                                     "per-lane branches (every lane computes, outcomes are selected), so lanes that stand at no node count as active",
                     "share_of_step_time": st["ms"] * 1e-3 / dt}
 
         pm_names = ("k_trace", "k_trace_shadow", "k_sweep", "k_sweep_shadow")

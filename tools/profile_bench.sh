@@ -13,4 +13,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o b -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o b -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU --output-format csv -d $O/sq -o b -- python3 $R/bench.py $ARGS > $O/sq.log 2>&1
-grep -h '"metric"' $O/*.log | head -4
+grep -h "\"metric\"" $O/*.log | cut -c1-160 | head -4
