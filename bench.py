@@ -309,7 +309,7 @@ def main():
                     "launches": st["launches"], "avg_launch_ms": avg_ms,
                     "algorithmic_ops_per_launch": alg / launches, "algorithmic_achieved": rate(alg) / 1e12, "algorithmic_frac": rate(alg) / VALU_FP64_PEAK,
                     "algorithmic_model": "the reference's walk priced per unit: 26 per slab test + 50 per primitive it tests (N_p), whether or not the box pre-tests let "
-                                         "the kernel skip that primitive -- a rate of useful work (what earlier rounds reported as frac), not bounded by 1",
+                                         "the kernel skip that primitive -- a rate of useful work (the figure this benchmark called frac before the pre-tests existed), not bounded by 1",
                     "rays": st["rays"], "inner_visits_per_ray": st["inner"] / rays, "leaf_visits_per_ray": st["leaf"] / rays,
                     "covered_prims_per_ray": st["prim"] / rays, "executed_fp64_tests_per_ray": st["fp64_tests"] / rays,
                     "executed_box_tests_per_ray": st["box_tests"] / rays,
