@@ -483,15 +483,17 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
                 const bool y_lt_x = am1 < am0, z_lt_x = am2 < am0, z_lt_y = am2 < am1;
                 // crossings that come before this axis's own
                 const bool ax = i1 & y_lt_x, bx = i2 & z_lt_x, ay = i0 & !y_lt_x, by = i2 & z_lt_y, az = i0 & !z_lt_x, bz = i1 & !z_lt_y;
-                // the half (0 low, 1 high) per axis in the first octant, and which axes have flipped by the second, third, fourth
+                // the half (0 low, 1 high) per axis in the first octant, and which axes have flipped by the
+                // second, third, fourth octant: four 3-bit fields of one word, worked on together
                 const uint32_t o0 = (uint32_t)((d.x < 0) != !g0) | (uint32_t)((d.y < 0) != !g1) << 1 | (uint32_t)((d.z < 0) != !g2) << 2;
-                const uint32_t f1 = (uint32_t)(i0 & !ax & !bx) | (uint32_t)(i1 & !ay & !by) << 1 | (uint32_t)(i2 & !az & !bz) << 2;
-                const uint32_t f2 = (uint32_t)(i0 & !(ax & bx)) | (uint32_t)(i1 & !(ay & by)) << 1 | (uint32_t)(i2 & !(az & bz)) << 2;
-                const uint32_t f3 = (uint32_t)i0 | (uint32_t)i1 << 1 | (uint32_t)i2 << 2;
-                cnt = 1u + (uint32_t)i0 + (uint32_t)i1 + (uint32_t)i2;
-                // x-half | y-half << 1 | z-half << 2  ->  child index in getChildBound's corner order (0 1 3 2 4 5 7 6)
-                auto kid = [](uint32_t oct) { return (0xDEC4C8u >> (3u * oct)) & 7u; };
-                order = kid(o0) | kid(o0 ^ f1) << 3 | kid(o0 ^ f2) << 6 | kid(o0 ^ f3) << 9;
+                const uint32_t flips = (uint32_t)(i0 & !ax & !bx) << 3 | (uint32_t)(i1 & !ay & !by) << 4 | (uint32_t)(i2 & !az & !bz) << 5 |
+                                       (uint32_t)(i0 & !(ax & bx)) << 6 | (uint32_t)(i1 & !(ay & by)) << 7 | (uint32_t)(i2 & !(az & bz)) << 8 |
+                                       (uint32_t)i0 << 9 | (uint32_t)i1 << 10 | (uint32_t)i2 << 11;
+                cnt = 1u + (uint32_t)__builtin_popcount(flips >> 9);
+                const uint32_t octs = (o0 * 0x249u) ^ flips;                // o0 in all four fields, then the flips
+                // x-half | y-half << 1 | z-half << 2  ->  child index in getChildBound's corner order
+                // (0 1 3 2 4 5 7 6): the x bit flips where the y bit is set
+                order = octs ^ ((octs >> 1) & 0x249u);
             }
         }
         if (long_way) {
