@@ -55,6 +55,15 @@ inline BoxD clipped_triangle_box(const LeafTri &t, const FlatNode &n)
     double ext = 0;
     for (int k = 0; k < 3; k++) { const double e = n.hi[k] - n.lo[k]; if (!(e <= ext)) ext = e; b.lo[k] = n.lo[k]; b.hi[k] = n.hi[k]; }
     if (!std::isfinite(ext) || !(ext > 0)) return b;
+    // A triangle whose corners lie (almost) on one line has no box: the double-precision test divides by a
+    // determinant that is rounding noise for it, so what it accepts need not lie near the triangle at all
+    // (corners on a lattice make exactly collinear triangles, and the test "hits" them at distance 0 from
+    // anywhere); with the whole-node box every ray that visits the node gets that test, as in the reference walk.
+    {
+        const double cx = t.e1[1] * t.e2[2] - t.e2[1] * t.e1[2], cy = t.e1[2] * t.e2[0] - t.e1[0] * t.e2[2], cz = t.e1[0] * t.e2[1] - t.e2[0] * t.e1[1];
+        const double l1 = t.e1[0] * t.e1[0] + t.e1[1] * t.e1[1] + t.e1[2] * t.e1[2], l2 = t.e2[0] * t.e2[0] + t.e2[1] * t.e2[1] + t.e2[2] * t.e2[2];
+        if (!(cx * cx + cy * cy + cz * cz > 1e-12 * l1 * l2)) return b;       // sine of the angle at v0 under 1e-6 (or not a number)
+    }
     const double grow = ext / 64;
     double poly[2][16][3];
     int cnt = 3, cur = 0;

@@ -278,6 +278,35 @@ def test_box_pretest_never_rejects_a_hit(case):
     assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
 
 
+def test_collinear_triangle_reaches_the_double_precision_test():
+    """A triangle with two corners in one place has no area, but the double-precision test divides by a
+    determinant that is rounding noise for it (its edge is not axis-aligned), and for this ray the noise
+    falls so that the triangle is "hit" at distance -0.0, from 0.7 units away.  The triangle sits in the
+    root's own list (it touches two of the root's splitting planes), so the reference walk tests it for every
+    ray that enters the mesh's box, and the device must make that test too: the box pre-test may not speak
+    for a triangle whose test does not follow its geometry."""
+    T = np.array([[0.125, 0.5, 0.5, 0.0, 0.375, 0.625, 0.0, 0.375, 0.625]])
+    fill = np.round(scenes.soup(60, seed=98, edge_lo=0.1, edge_hi=0.3) * 8.0) / 8.0
+    c0 = np.array([[-0.125, -0.125, -0.125, 0, -0.125, -0.125, -0.125, 0, -0.125]])         # pin the mesh's bounds to [-1/8, 9/8]^3
+    c1 = np.array([[1.125, 1.125, 1.125, 1, 1.125, 1.125, 1.125, 1, 1.125]])
+    desc = _mesh_desc(np.ascontiguousarray(np.concatenate([fill[:30], T, fill[30:], c0, c1])), octree_max_size=4, octree_max_depth=10)
+    so, sg = orc.OracleScene(desc), hip.HipScene(desc)
+    assert so.octree_stats(0) == sg.octree_stats(0)
+    rays = np.zeros(1, RAY_DT)
+    rays["e"] = [0.9286631233312823, 0.07916902727209418, 0.3983703657320463]
+    rays["d"] = [-0.6274751611070144, 0.7602633351402673, -0.16815047854562842]
+    p1, d1, n1, c1_ = so.trace_rays(rays, 0.0, 1e30)
+    assert p1[0] == 30 and d1[0] == 0.0 and np.signbit(d1[0]) and np.isnan(n1).all()        # the case is what it is meant to be
+    p2, d2, n2, c2_ = sg.trace_rays(rays, 0.0, 1e30)
+    assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.signbit(d2[0]) and np.isnan(n2).all() and np.array_equal(c1_, c2_)
+    # and among many rays through the same mesh
+    more = _rays(np.random.default_rng(98), 20000, -0.1, 1.1)
+    more[0] = rays[0]
+    p1, d1, n1, c1_ = so.trace_rays(more, 0.0, 1e30)
+    p2, d2, n2, c2_ = sg.trace_rays(more, 0.0, 1e30)
+    assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2, equal_nan=True) and np.array_equal(c1_, c2_)
+
+
 def test_primary_id_buffer_bit_exact_small():
     desc, cam = scenes.soup_scene(50000, seed=9)
     so, sg = orc.OracleScene(desc), hip.HipScene(desc)
