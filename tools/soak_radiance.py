@@ -1,0 +1,165 @@
+"""Randomised differential run of the HIP path tracer against the CPU oracle (development aid; run on the
+GPU box): random small scenes -- spheres, planes, blob and soup meshes, Monte-Carlo materials with any
+mix of the diffuse, mirror (sharp or blurred) and dielectric lobes or Phong materials, one to three
+lights of the three kinds -- and random rays through `ray_color`, the per-path entry point.  The numbers
+of rays traced must be the oracle's exactly for shallow path trees (see below for deep ones), the radiance
+of every path within the per-path tolerance.  Prints one line per scene and stops at the first difference.
+
+    python tools/soak_radiance.py --seconds 240 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import orc  # noqa: E402  (the checker)
+from raytracer_amd import hip, scenes  # noqa: E402
+from raytracer_amd.desc import (LIGHT_DT, MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MATERIAL_DT, OBJ_GROUND, OBJECT_DT, RAY_DT,  # noqa: E402
+                                SceneDesc, render_params)
+
+PATH_RTOL = 1e-4
+
+
+def random_material(rng, phong_ok):
+    if phong_ok and rng.random() < 0.25:
+        return scenes.phong_material(ambient=tuple(rng.uniform(0, .3, 3)), diffuse=tuple(rng.uniform(.1, .9, 3)), specular=tuple(rng.uniform(0, .8, 3)),
+                                     shine=float(rng.uniform(1, 40)), mirror=tuple(rng.uniform(0, .6, 3)) if rng.random() < 0.4 else None)
+    kind = 0
+    while kind == 0:
+        kind = (MAT_NORMAL if rng.random() < 0.7 else 0) | (MAT_SPECULAR if rng.random() < 0.3 else 0) | (MAT_TRANSPARENT if rng.random() < 0.25 else 0)
+    return scenes.material(kind, emission=tuple(rng.uniform(0, .3, 3)) if rng.random() < 0.2 else (0, 0, 0), color=tuple(rng.uniform(.2, .95, 3)),
+                           blur=float(rng.uniform(0.01, 0.3)) if rng.random() < 0.3 else 0.0, atten=tuple(rng.uniform(0, .3, 3)), nr=float(rng.uniform(1.1, 1.8)))
+
+
+def random_scene(rng):
+    phong_ok = rng.random() < 0.4
+    nmat = int(rng.integers(2, 6))
+    mats = [random_material(rng, phong_ok) for _ in range(nmat)]
+    objs, meshes = [], []
+    objs.append(scenes.plane(OBJ_GROUND, 0.0, int(rng.integers(nmat))))
+    for _ in range(int(rng.integers(1, 5))):
+        r = float(rng.uniform(0.3, 1.2))
+        objs.append(scenes.sphere((float(rng.uniform(-3, 3)), r + float(rng.uniform(0, 1.5)), float(rng.uniform(-3, 3))), r, int(rng.integers(nmat))))
+    for _ in range(int(rng.integers(0, 3))):
+        if rng.random() < 0.6:
+            nu = int(rng.integers(6, 40))
+            tris = scenes.blob((float(rng.uniform(-3, 3)), float(rng.uniform(1, 2.5)), float(rng.uniform(-3, 3))), float(rng.uniform(0.5, 1.2)), nu, nu + 1, seed=int(rng.integers(1 << 30)))
+        else:
+            tris = scenes.soup(int(rng.integers(50, 4000)), seed=int(rng.integers(1 << 30)), edge_lo=0.02, edge_hi=0.25) * 3.0 + np.tile((-1.5, 0.2, -1.5), 3)
+        objs.append(scenes.mesh_object(len(meshes), int(rng.integers(nmat))))
+        meshes.append(np.ascontiguousarray(tris))
+    lights = []
+    for _ in range(int(rng.integers(1, 4))):
+        k = rng.random()
+        pos = (float(rng.uniform(-4, 4)), float(rng.uniform(4, 7)), float(rng.uniform(-4, 4)))
+        if k < 0.4:
+            rad = float(rng.uniform(0.2, 0.9))
+            em = tuple(rng.uniform(5, 30, 3))
+            lights.append(scenes.sphere_light(pos, rad, em))
+            mats.append(scenes.material(MAT_NORMAL, emission=em, color=(0, 0, 0)))
+            objs.append(scenes.sphere(pos, rad, len(mats) - 1))                  # Scene::addLight appends the light's geometry
+        elif k < 0.8:
+            lights.append(scenes.face_light(pos, (float(rng.uniform(-.5, .5)), -1, float(rng.uniform(-.5, .5))), (0, 0, 1), float(rng.uniform(.5, 3)), float(rng.uniform(.5, 3)),
+                                            tuple(rng.uniform(3, 15, 3)), ambient=tuple(rng.uniform(0, .3, 3)), specular=tuple(rng.uniform(0, 1, 3))))
+        else:
+            lights.append(scenes.point_light(pos, tuple(rng.uniform(0, .4, 3)), tuple(rng.uniform(.3, 1, 3)), tuple(rng.uniform(0, 1, 3))))
+    desc = SceneDesc(scenes._stack(objs, OBJECT_DT), scenes._stack(mats, MATERIAL_DT), scenes._stack(lights, LIGHT_DT), meshes,
+                     background=tuple(rng.uniform(0, .3, 3)), octree_max_size=int(rng.choice([4, 16, 64, 128])))
+    return desc
+
+
+def random_rays(rng, n):
+    r = np.zeros(n, RAY_DT)
+    e = np.stack([rng.uniform(-6, 6, n), rng.uniform(0.3, 6, n), rng.uniform(-6, 6, n)], axis=1)
+    target = np.stack([rng.uniform(-3, 3, n), rng.uniform(0, 3, n), rng.uniform(-3, 3, n)], axis=1)
+    d = target - e
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r["e"], r["d"] = e, d
+    return r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=6000)
+    ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--oracle-only", action="store_true", help="build the scenes and run the oracle alone (checks this script without a GPU)")
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t_end = time.time() + a.seconds
+    k = 0
+    worst = 0.0
+    while time.time() < t_end:
+        desc = random_scene(rng)
+        rays = random_rays(rng, a.rays)
+        prm = render_params(64, 64, int(rng.integers(1, 4)), seed=int(rng.integers(1 << 30)), max_jump=int(rng.integers(2, 14)), rus_jump=int(rng.integers(1, 8)),
+                            face_forward=bool(rng.random() < 0.3))
+        if a.only >= 0 and k != a.only:
+            k += 1
+            if k > a.only:
+                break
+            continue
+        so = orc.OracleScene(desc)
+        sg = so if a.oracle_only else hip.HipScene(desc)
+        # glass among mirrors can make millions of rays from one: keep a scene to what the oracle does in seconds
+        _, kp = so.ray_color(rays[:100], prm)
+        if int(kp[0]) * (len(rays) / 100.0) > 3e6:
+            rays = rays[:max(100, int(len(rays) * 3e6 / (int(kp[0]) * (len(rays) / 100.0))))]
+        c1, k1 = so.ray_color(rays, prm)
+        c2, k2 = sg.ray_color(rays, prm)
+        # a path may be not-a-number on both sides (the Phong term raises a negative cosine to a fractional power,
+        # scene.cpp:316-318): then it must be so on both
+        nan1, nan2 = ~np.isfinite(c1), ~np.isfinite(c2)
+        f1, f2 = np.where(nan1, 0.0, c1), np.where(nan2, 0.0, c2)
+        rel = np.abs(f1 - f2) / np.maximum(1e-9, np.maximum(np.abs(f1), np.abs(f2)))
+        r = rel.max(axis=1) if len(rel) else np.zeros(0)
+        worst = max(worst, float(r.max()) if len(r) else 0.0)
+        # The device's sin / cos / exp / pow differ from glibc's in the last bit, and a chain of reflections and
+        # refractions on curved surfaces multiplies such a difference by a few units per vertex: ten vertices down,
+        # one ray in 10^5 grazes an edge on one side and misses it on the other (seen: 7522 against 7520 rays at
+        # depth 12 of one path, equal counts at every smaller depth limit, radiance equal to 3e-15).  Shallow
+        # trees must have identical counts; deep ones may differ in the ray count by 1e-5 of it.
+        same_tree = np.array_equal(k1, k2) if int(prm.max_jump) <= 6 else abs(int(k1[0]) - int(k2[0])) <= 1e-5 * int(k1[0])
+        if not same_tree or (r > PATH_RTOL).any() or not np.array_equal(nan1, nan2):
+            bad = np.nonzero(r > PATH_RTOL)[0]
+            print("DIFFERENCE in scene", k, "seed", a.seed, "counters", k1.tolist(), k2.tolist(), "paths over tolerance", bad[:10].tolist(), "max rel", float(r.max()),
+                  "not finite", int(nan1.sum()), int(nan2.sum()), flush=True)
+            for i in bad[:3]:
+                print(" ray", i, rays[i]["e"].tolist(), rays[i]["d"].tolist(), "oracle", c1[i].tolist(), "device", c2[i].tolist(), flush=True)
+            if not same_tree:
+                # which paths trace different numbers of rays: halve the batch until single rays are left
+                todo, found = [(0, len(rays))], []
+                while todo and len(found) < 4:
+                    lo, hi = todo.pop()
+                    # a ray's place in the batch keys its random numbers: the other rays are replaced by rays into the sky
+                    sub = rays.copy()
+                    sub["e"], sub["d"] = (0.0, 1000.0, 0.0), (0.0, 1.0, 0.0)
+                    sub[lo:hi] = rays[lo:hi]
+                    ca, ka = so.ray_color(sub, prm)
+                    cb, kb = sg.ray_color(sub, prm)
+                    if np.array_equal(ka, kb):
+                        continue
+                    if hi - lo == 1:
+                        found.append(lo)
+                        print(" path", lo, "e", rays[lo]["e"].tolist(), "d", rays[lo]["d"].tolist(), "counters", ka.tolist(), kb.tolist(), "radiance", ca[lo].tolist(), cb[lo].tolist(), flush=True)
+                        # the shallowest depth limit at which the two sides part
+                        for mj in range(1, int(prm.max_jump) + 1):
+                            q = render_params(int(prm.width), int(prm.height), int(prm.n), seed=int(prm.seed), max_jump=mj, rus_jump=int(prm.rus_jump), face_forward=bool(prm.face_forward))
+                            _, kc = so.ray_color(sub, q)
+                            _, kd = sg.ray_color(sub, q)
+                            print("  max_jump", mj, "rays", int(kc[0]) - (len(sub) - 1), int(kd[0]) - (len(sub) - 1), flush=True)
+                    else:
+                        mid = (lo + hi) // 2
+                        todo += [(mid, hi), (lo, mid)]
+            sys.exit(1)
+        print(f"scene {k}: objects {len(desc.objects)} meshes {[len(m) for m in desc.meshes]} lights {len(desc.lights)} rays traced {int(k1[0])} mean {float(f1.mean()):.3f} nan {int(nan1.any(axis=1).sum())} max rel {float(r.max()):.1e} ok", flush=True)
+        k += 1
+    print("all", k, "scenes within tolerance; worst relative difference", worst, flush=True)
+
+
+if __name__ == "__main__":
+    main()
