@@ -16,7 +16,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import orc  # noqa: E402  (the checker)
 from raytracer_amd import hip, scenes  # noqa: E402
-from raytracer_amd.desc import LIGHT_DT, MAT_NORMAL, MATERIAL_DT, MISS, OBJ_GROUND, OBJECT_DT, RAY_DT, SceneDesc  # noqa: E402
+from raytracer_amd.desc import LIGHT_DT, MAT_NORMAL, MATERIAL_DT, MISS, OBJ_GENUS2, OBJ_GROUND, OBJ_HEART, OBJECT_DT, RAY_DT, SceneDesc  # noqa: E402
+
+IMPLICIT_SHARE = 0.0          # share of the scenes that hold implicit surfaces (--implicit)
 
 
 def random_scene(rng):
@@ -40,6 +42,14 @@ def random_scene(rng):
         if rng.random() < 0.3:
             objs.append(scenes.plane(OBJ_GROUND, float(rng.uniform(-1, 0)), 0))
     kw = dict(octree_max_size=int(rng.choice([2, 4, 8, 16, 32, 64, 128])), octree_max_depth=int(rng.integers(3, 16)))
+    if rng.random() < IMPLICIT_SHARE:
+        # one or two implicit surfaces (voxel octrees) among the meshes, about as large as they are
+        allv = np.concatenate([m.reshape(-1, 3) for m in meshes])
+        lo, hi = allv.min(axis=0), allv.max(axis=0)
+        for _ in range(int(rng.integers(1, 3))):
+            objs.insert(int(rng.integers(0, len(objs) + 1)),
+                        scenes.implicit_object(OBJ_HEART if rng.random() < 0.5 else OBJ_GENUS2, tuple(rng.uniform(lo, hi)), float(max(np.max(hi - lo), 1e-3) * rng.uniform(0.15, 0.5)), 0))
+        kw["implicit_min_size"] = float(rng.uniform(2e-2, 5e-2))
     desc = SceneDesc(scenes._stack(objs, OBJECT_DT), mats, np.zeros(0, LIGHT_DT), meshes, **kw)
     return desc, meshes, kw
 
@@ -85,9 +95,12 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rays", type=int, default=20000)
+    ap.add_argument("--implicit", type=float, default=0.0, help="share of the scenes with one or two implicit surfaces among the meshes")
     ap.add_argument("--only", type=int, default=-1, help="evaluate this scene of the sequence alone")
     ap.add_argument("--oracle-only", action="store_true", help="build the scenes and run the oracle alone (checks this script without a GPU)")
     a = ap.parse_args()
+    global IMPLICIT_SHARE
+    IMPLICIT_SHARE = a.implicit
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
     k = 0
