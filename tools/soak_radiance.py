@@ -134,7 +134,7 @@ def main():
         # one ray in 10^5 grazes an edge on one side and misses it on the other (seen: 7522 against 7520 rays at
         # depth 12 of one path, equal counts at every smaller depth limit, radiance equal to 3e-15).  Shallow
         # trees must have identical counts; deep ones may differ in the ray count by 1e-5 of it.
-        same_tree = np.array_equal(k1, k2) if int(prm.max_jump) <= 6 else abs(int(k1[0]) - int(k2[0])) <= 1e-5 * int(k1[0])
+        same_tree = np.array_equal(k1, k2) if int(prm.max_jump) <= 5 else abs(int(k1[0]) - int(k2[0])) <= 1e-5 * int(k1[0])
         if not same_tree or (r > PATH_RTOL).any() or not np.array_equal(nan1, nan2):
             bad = np.nonzero(r > PATH_RTOL)[0]
             print("DIFFERENCE in scene", k, "seed", a.seed, "counters", k1.tolist(), k2.tolist(), "paths over tolerance", bad[:10].tolist(), "max rel", float(r.max()),
