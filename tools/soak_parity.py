@@ -132,6 +132,18 @@ def main():
                          rays=rays[bad[:16]], objects=desc.objects, t0=t0, t1=t1, max_size=kw["octree_max_size"], max_depth=kw["octree_max_depth"],
                          **{f"mesh{j}": m for j, m in enumerate(meshes)})
                 sys.exit(1)
+        # the primary-ray id buffer through a camera that looks at the meshes (single-precision pixel coordinates)
+        allv = np.concatenate([m.reshape(-1, 3) for m in meshes])
+        mid, span = (allv.min(axis=0) + allv.max(axis=0)) / 2, float(max(np.ptp(allv), 1e-3))
+        eye = mid + rng.normal(size=3) * span * float(rng.uniform(0.2, 2.0))
+        if np.linalg.norm(np.cross(mid - eye, (0, 1, 0))) > 1e-6 * span:
+            W, H = int(rng.integers(16, 200)), int(rng.integers(16, 200))
+            cam = hip.camera_init(tuple(eye), tuple(mid), (0, 1, 0), float(rng.uniform(10, 100)), W / H)
+            a1, b1, q1 = so.trace_primary(cam, W, H)
+            a2, b2, q2 = sg.trace_primary(cam, W, H)
+            if not (np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(q1, q2)):
+                print("DIFFERENCE in scene", k, "seed", a.seed, kw, "primary rays", (W, H), "pixels", np.nonzero((a1 != a2) | (b1 != b2))[0][:10], "counters", q1, q2, flush=True)
+                sys.exit(1)
         print(f"scene {k}: meshes {[len(m) for m in meshes]} objects {len(desc.objects)} {kw} hit {float((p1 != MISS).mean()):.2f} counters {c1.tolist()} ok", flush=True)
         k += 1
     print("all", k, "scenes identical", flush=True)

@@ -17,7 +17,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import orc  # noqa: E402  (the checker)
 from raytracer_amd import hip, scenes  # noqa: E402
-from raytracer_amd.desc import (LIGHT_DT, MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MATERIAL_DT, OBJ_GROUND, OBJECT_DT, RAY_DT,  # noqa: E402
+from raytracer_amd.desc import (LIGHT_DT, MAT_NORMAL, MAT_SPECULAR, MAT_TRANSPARENT, MATERIAL_DT, OBJ_GENUS2, OBJ_GROUND, OBJ_HEART, OBJECT_DT, RAY_DT,  # noqa: E402
                                 SceneDesc, render_params)
 
 PATH_RTOL = 1e-4
@@ -51,6 +51,12 @@ def random_scene(rng):
             tris = scenes.soup(int(rng.integers(50, 4000)), seed=int(rng.integers(1 << 30)), edge_lo=0.02, edge_hi=0.25) * 3.0 + np.tile((-1.5, 0.2, -1.5), 3)
         objs.append(scenes.mesh_object(len(meshes), int(rng.integers(nmat))))
         meshes.append(np.ascontiguousarray(tris))
+    kw = {}
+    if rng.random() < 0.2:
+        # an implicit surface (voxel octree, analytic normals) among the objects
+        objs.insert(int(rng.integers(1, len(objs) + 1)), scenes.implicit_object(OBJ_HEART if rng.random() < 0.5 else OBJ_GENUS2,
+                                                                                 (float(rng.uniform(-2, 2)), float(rng.uniform(1, 2)), float(rng.uniform(-2, 2))), float(rng.uniform(0.5, 1.0)), int(rng.integers(nmat))))
+        kw["implicit_min_size"] = float(rng.uniform(2.5e-2, 5e-2))
     lights = []
     for _ in range(int(rng.integers(1, 4))):
         k = rng.random()
@@ -67,7 +73,7 @@ def random_scene(rng):
         else:
             lights.append(scenes.point_light(pos, tuple(rng.uniform(0, .4, 3)), tuple(rng.uniform(.3, 1, 3)), tuple(rng.uniform(0, 1, 3))))
     desc = SceneDesc(scenes._stack(objs, OBJECT_DT), scenes._stack(mats, MATERIAL_DT), scenes._stack(lights, LIGHT_DT), meshes,
-                     background=tuple(rng.uniform(0, .3, 3)), octree_max_size=int(rng.choice([4, 16, 64, 128])))
+                     background=tuple(rng.uniform(0, .3, 3)), octree_max_size=int(rng.choice([4, 16, 64, 128])), **kw)
     return desc
 
 
