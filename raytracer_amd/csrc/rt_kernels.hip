@@ -18,6 +18,7 @@ namespace rt {
 #define RT_ZERO 1e-9         // definitions.h:6
 #define RT_PI 3.1415926      // definitions.h:7
 #define TRI_DET_EPS 1e-200
+#define TRI_PARALLEL2 1e-12   // (sine of the angle between e1 and d x e2)^2 below which the determinant counts as zero
 
 struct V3 { double x, y, z; };
 __device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -155,6 +156,10 @@ __device__ __forceinline__ bool tri_hit(const TriReg &tr, V3 e, V3 d, double t0,
     double det = dot(e1, p);
     double a = fabs(det);
     if (!(a >= TRI_DET_EPS)) return false;
+    // a determinant that is rounding noise -- the ray runs in the triangle's plane, or the triangle has no
+    // area -- is no hit: the quotients below would be noise over noise (a ray between lattice points in the
+    // plane of a lattice triangle has numerators of exactly zero and "hits" at t = 0, wherever the triangle is)
+    if (!(det * det >= TRI_PARALLEL2 * dot(e1, e1) * dot(p, p))) return false;
     V3 s = e - v0;
     double up = dot(s, p);
     double us = det < 0 ? -up : up;

@@ -278,30 +278,41 @@ def test_box_pretest_never_rejects_a_hit(case):
     assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2) and np.array_equal(c1, c2)
 
 
-def test_collinear_triangle_reaches_the_double_precision_test():
-    """A triangle with two corners in one place has no area, but the double-precision test divides by a
-    determinant that is rounding noise for it (its edge is not axis-aligned), and for this ray the noise
-    falls so that the triangle is "hit" at distance -0.0, from 0.7 units away.  The triangle sits in the
-    root's own list (it touches two of the root's splitting planes), so the reference walk tests it for every
-    ray that enters the mesh's box, and the device must make that test too: the box pre-test may not speak
-    for a triangle whose test does not follow its geometry."""
+def test_determinants_that_are_rounding_noise_are_no_hits():
+    """Two inputs whose Moeller-Trumbore determinant is rounding noise instead of the zero it stands for, so that
+    the quotients of the test are noise over noise: a triangle with two corners in one place (its edge is not
+    axis-aligned, so the products do not cancel exactly), which used to be "hit" at distance -0.0 by this ray
+    from 0.7 units away; and a ray between two lattice points that runs in the plane of a lattice triangle it
+    does not touch, with numerators of exactly zero, which used to "hit" it at t = 0.  Both are rejected by the
+    test itself now (the determinant must stand clear of its own rounding error), on both sides alike; before,
+    the oracle accepted them and the device's box pre-test, which follows the geometry, did not."""
     T = np.array([[0.125, 0.5, 0.5, 0.0, 0.375, 0.625, 0.0, 0.375, 0.625]])
     fill = np.round(scenes.soup(60, seed=98, edge_lo=0.1, edge_hi=0.3) * 8.0) / 8.0
     c0 = np.array([[-0.125, -0.125, -0.125, 0, -0.125, -0.125, -0.125, 0, -0.125]])         # pin the mesh's bounds to [-1/8, 9/8]^3
     c1 = np.array([[1.125, 1.125, 1.125, 1, 1.125, 1.125, 1.125, 1, 1.125]])
-    desc = _mesh_desc(np.ascontiguousarray(np.concatenate([fill[:30], T, fill[30:], c0, c1])), octree_max_size=4, octree_max_depth=10)
+    # the lattice triangle of the second case: normal (1, 1, 2), in the plane x + y + 2 z = 15/8
+    P = np.array([[0.15625, 0.46875, 0.625, 0.09375, 0.46875, 0.65625, 0.125, 0.4375, 0.65625]])
+    desc = _mesh_desc(np.ascontiguousarray(np.concatenate([fill[:30], T, fill[30:], P, c0, c1])), octree_max_size=4, octree_max_depth=10)
     so, sg = orc.OracleScene(desc), hip.HipScene(desc)
     assert so.octree_stats(0) == sg.octree_stats(0)
-    rays = np.zeros(1, RAY_DT)
-    rays["e"] = [0.9286631233312823, 0.07916902727209418, 0.3983703657320463]
-    rays["d"] = [-0.6274751611070144, 0.7602633351402673, -0.16815047854562842]
+    rays = np.zeros(2, RAY_DT)
+    rays["e"][0] = [0.9286631233312823, 0.07916902727209418, 0.3983703657320463]
+    rays["d"][0] = [-0.6274751611070144, 0.7602633351402673, -0.16815047854562842]
+    rays["e"][1] = [0.125, 0.25, 0.75]                                                      # in the plane, direction (5, 1, -3) / sqrt(35)
+    rays["d"][1] = [0.8451542547285166, 0.1690308509457033, -0.50709255283711]
+    assert orc.triangle_hit(T[0], rays["e"][0], rays["d"][0], 0.0, 1e30)[0] == 0
+    assert orc.triangle_hit(P[0], rays["e"][1], rays["d"][1], 0.0, 1e30)[0] == 0
     p1, d1, n1, c1_ = so.trace_rays(rays, 0.0, 1e30)
-    assert p1[0] == 30 and d1[0] == 0.0 and np.signbit(d1[0]) and np.isnan(n1).all()        # the case is what it is meant to be
     p2, d2, n2, c2_ = sg.trace_rays(rays, 0.0, 1e30)
-    assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.signbit(d2[0]) and np.isnan(n2).all() and np.array_equal(c1_, c2_)
-    # and among many rays through the same mesh
+    assert p1[0] != 30 and p1[1] != 61
+    assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2, equal_nan=True) and np.array_equal(c1_, c2_)
+    # and among many rays through the same mesh, a fifth of them between lattice points
     more = _rays(np.random.default_rng(98), 20000, -0.1, 1.1)
-    more[0] = rays[0]
+    rng = np.random.default_rng(99)
+    a, b = np.round(rng.uniform(0, 1, (4000, 3)) * 8) / 8, np.round(rng.uniform(0, 1, (4000, 3)) * 8) / 8
+    ok = np.linalg.norm(b - a, axis=1) > 0
+    more["e"][:4000][ok] = a[ok]
+    more["d"][:4000][ok] = ((b - a) / np.maximum(np.linalg.norm(b - a, axis=1, keepdims=True), 1e-300))[ok]
     p1, d1, n1, c1_ = so.trace_rays(more, 0.0, 1e30)
     p2, d2, n2, c2_ = sg.trace_rays(more, 0.0, 1e30)
     assert np.array_equal(p1, p2) and np.array_equal(d1, d2) and np.array_equal(n1, n2, equal_nan=True) and np.array_equal(c1_, c2_)

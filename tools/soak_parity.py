@@ -35,6 +35,10 @@ def random_scene(rng):
         if rng.random() < 0.3:                                    # vertices on a coarse lattice: many exact coincidences with splitting planes
             q = float(2.0 ** -int(rng.integers(2, 7)))
             tris = np.round(tris / q) * q
+            if rng.random() < 0.5:
+                # ... and moved off it by next to nothing: triangles that are collinear, or coplanar with a
+                # splitting plane, to within 1e-13 .. 1e-4
+                tris = tris + rng.normal(size=tris.shape) * float(10.0 ** -int(rng.integers(4, 14)))
         if rng.random() < 0.3:
             tris = tris * float(np.exp(rng.uniform(np.log(1e-3), np.log(1e3)))) + np.tile(rng.uniform(-1, 1, 3) * float(np.exp(rng.uniform(0, np.log(1e4)))), 3)
         meshes.append(np.ascontiguousarray(tris))
@@ -84,6 +88,15 @@ def random_rays(rng, meshes, n):
     z2 = rng.integers(0, 3, n)
     two = ax & (rng.random(n) < 0.3) & (z2 != z)
     d[two, z2[two]] = 0.0
+    # a fifth of the rays between points of the 1/8 lattice (exactly rational directions, origins on splitting planes)
+    lat = rng.random(n) < 0.2
+    pts = np.round(rng.uniform(lo, hi, (n, 3)) * 8.0) / 8.0
+    pts2 = np.round(rng.uniform(lo, hi, (n, 3)) * 8.0) / 8.0
+    dl = pts2 - pts
+    nl = np.linalg.norm(dl, axis=1, keepdims=True)
+    lat &= nl[:, 0] > 0
+    e[lat] = pts[lat]
+    d[lat] = (dl / np.maximum(nl, 1e-300))[lat]
     bad = np.linalg.norm(d, axis=1) == 0
     d[bad] = (0, 0, 1)
     r["e"], r["d"] = e, d
@@ -106,15 +119,15 @@ def main():
     k = 0
     while time.time() < t_end:
         desc, meshes, kw = random_scene(rng)
+        rays = random_rays(rng, meshes, a.rays)
+        cam_draw = (rng.normal(size=3), float(rng.uniform(0.2, 2.0)), int(rng.integers(16, 200)), int(rng.integers(16, 200)), float(rng.uniform(10, 100)))
         if a.only >= 0 and k != a.only:
-            random_rays(rng, meshes, a.rays)
             k += 1
             if k > a.only:
                 break
             continue
         so = orc.OracleScene(desc)
         sg = so if a.oracle_only else hip.HipScene(desc)
-        rays = random_rays(rng, meshes, a.rays)
         ext = float(np.ptp(np.concatenate([m.reshape(-1, 3) for m in meshes])))
         for t0, t1 in ((0.0, 1e30), (1e-9 * ext, 0.7 * ext)):
             p1, d1, n1, c1 = so.trace_rays(rays, t0, t1)
@@ -135,10 +148,10 @@ def main():
         # the primary-ray id buffer through a camera that looks at the meshes (single-precision pixel coordinates)
         allv = np.concatenate([m.reshape(-1, 3) for m in meshes])
         mid, span = (allv.min(axis=0) + allv.max(axis=0)) / 2, float(max(np.ptp(allv), 1e-3))
-        eye = mid + rng.normal(size=3) * span * float(rng.uniform(0.2, 2.0))
+        eye = mid + cam_draw[0] * span * cam_draw[1]
         if np.linalg.norm(np.cross(mid - eye, (0, 1, 0))) > 1e-6 * span:
-            W, H = int(rng.integers(16, 200)), int(rng.integers(16, 200))
-            cam = hip.camera_init(tuple(eye), tuple(mid), (0, 1, 0), float(rng.uniform(10, 100)), W / H)
+            W, H = cam_draw[2], cam_draw[3]
+            cam = hip.camera_init(tuple(eye), tuple(mid), (0, 1, 0), cam_draw[4], W / H)
             a1, b1, q1 = so.trace_primary(cam, W, H)
             a2, b2, q2 = sg.trace_primary(cam, W, H)
             if not (np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(q1, q2)):
