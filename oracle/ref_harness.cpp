@@ -69,7 +69,7 @@ public:
         double det = e1_ * p;
         double a = fabs(det);
         if (!(a >= 1e-200)) return false;
-        if (!(det * det >= 1e-12 * (e1_ * e1_) * (p * p))) return false;      // a determinant that is rounding noise is no hit
+        if (!(det * det >= 1e-10 * (e1_ * e1_) * (e2_ * e2_) * (ray.d * ray.d))) return false;      // a determinant near its rounding error is no hit
         Vec3 s = ray.e - v0_;
         double up = s * p;
         double us = det < 0 ? -up : up;

@@ -260,16 +260,17 @@ int orc_plane_hit(int type, double coord, const orc_ray *r, double t0, double t1
  * a multiplication by 1/det), so the only division is the one that produces t for a ray that
  * passed them.  Takes the place of BoxNode::calHit (Surface.cpp:43-59) as the octree payload. */
 #define TRI_DET_EPS 1e-200
-#define TRI_PARALLEL2 1e-12
+#define TRI_GUARD2 1e-10
 static int triangle_hit(v3 v0, v3 e1, v3 e2, ray_t r, double t0, double t1, double *tout)
 {
     v3 p = vcross(r.d, e2);
     double det = vdot(e1, p);
     double a = fabs(det);
     if (!(a >= TRI_DET_EPS)) return 0;
-    /* a determinant that is rounding noise (the ray runs in the triangle's plane, or the triangle has no
-     * area) is no hit: the quotients below would be noise over noise */
-    if (!(det * det >= TRI_PARALLEL2 * vdot(e1, e1) * vdot(p, p))) return 0;
+    /* a determinant within a few orders of its rounding error (the ray runs in the triangle's plane, or the
+     * triangle has no area: sine of its angle at v0 times cosine between ray and normal under 1e-5) is no hit:
+     * the quotients below would be noise over noise */
+    if (!(det * det >= TRI_GUARD2 * vdot(e1, e1) * vdot(e2, e2) * vdot(r.d, r.d))) return 0;
     v3 s = vsub(r.e, v0);
     double up = vdot(s, p);
     double us = det < 0 ? -up : up;

@@ -14,6 +14,13 @@ namespace rt {
 // (rt_pretest.h); two boxes to a 16-byte load.
 #define RT_GRID_EDGE 127u
 #define RT_GRID_ORG 64u
+// The boxes are grown by RT_BOX_GROW grid units before they are rounded outwards to bytes: 2e-3 for the
+// single-precision arithmetic of the box test itself, the rest for the double-precision primitive test, whose
+// accepted points lie within 64 ulp * reach / 1e-5 of the primitive (see tri_hit) -- 2.8e-2 units for a ray
+// whose reach is RT_REACH_GRID units of the node's grid.  A ray that reaches farther is not pre-tested in
+// that node (node_step).
+#define RT_BOX_GROW 3.2e-2
+#define RT_REACH_GRID 4.0e7f
 #define RT_BOX_SPARE 64          // spare boxes after the last record: a chunk of 64 is read from any record on without clamping
 #ifndef RT_SEG_RECS
 #define RT_SEG_RECS 16

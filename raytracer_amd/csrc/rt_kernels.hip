@@ -18,7 +18,7 @@ namespace rt {
 #define RT_ZERO 1e-9         // definitions.h:6
 #define RT_PI 3.1415926      // definitions.h:7
 #define TRI_DET_EPS 1e-200
-#define TRI_PARALLEL2 1e-12   // (sine of the angle between e1 and d x e2)^2 below which the determinant counts as zero
+#define TRI_GUARD2 1e-10      // (sine of the triangle's angle at v0 * cosine between ray and normal)^2 below which the determinant counts as zero
 
 struct V3 { double x, y, z; };
 __device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -156,10 +156,13 @@ __device__ __forceinline__ bool tri_hit(const TriReg &tr, V3 e, V3 d, double t0,
     double det = dot(e1, p);
     double a = fabs(det);
     if (!(a >= TRI_DET_EPS)) return false;
-    // a determinant that is rounding noise -- the ray runs in the triangle's plane, or the triangle has no
-    // area -- is no hit: the quotients below would be noise over noise (a ray between lattice points in the
-    // plane of a lattice triangle has numerators of exactly zero and "hits" at t = 0, wherever the triangle is)
-    if (!(det * det >= TRI_PARALLEL2 * dot(e1, e1) * dot(p, p))) return false;
+    // A determinant within a few orders of its own rounding error is no hit: det = |d| |e1| |e2| * (sine of
+    // the triangle's angle at v0) * (cosine between ray and normal), and the test wants that product of sine
+    // and cosine to reach 1e-5.  Below it the quotients are noise over noise (a ray between lattice points in
+    // the plane of a lattice triangle has numerators of exactly zero and "hits" at t = 0, wherever the
+    // triangle is); above it the point the test accepts lies within 64 ulp * (distance + coordinates) / 1e-5
+    // of the triangle, which is what the boxes of the pre-test are grown by (RT_BOX_GROW, RT_REACH_GRID).
+    if (!(det * det >= TRI_GUARD2 * dot(e1, e1) * dot(e2, e2) * dot(d, d))) return false;
     V3 s = e - v0;
     double up = dot(s, p);
     double us = det < 0 ? -up : up;
@@ -303,7 +306,7 @@ __device__ __forceinline__ bool org_is_regular(V3 e) { return coord_is_regular(e
 // whether the 80-byte record is fetched and the fp64 test made at all; the same test against the
 // box of a whole segment of a run decides whether the segment's records are looked at at all.  The
 // boxes are bytes in the grid of the node that owns the run (rt_pretest.h), rounded outwards by at
-// least 2e-3 grid units at build time, around the part of the primitive inside the node's box.
+// least RT_BOX_GROW grid units at build time, around the part of the primitive inside the node's box.
 // The ray is taken into that grid when the run opens: g = the point where it enters the node's box
 // (at most 256 units from the grid's origin), n = its unit direction; a point of the ray is
 // g + tau * n, and the stretch inside the node's box is 0 <= tau <= tend.  Slab test per axis:
@@ -313,11 +316,14 @@ __device__ __forceinline__ bool org_is_regular(V3 e) { return coord_is_regular(e
 // Errors, each expressed as the shift of a plane that would have the same effect: g is rounded to
 // single precision (3e-5 units, the arithmetic that forms it included), the direction too (1e-7 rad
 // over at most 450 units: 5e-5), c and the fused multiply-add round once each (6e-8 of at most 450
-// units: 3e-5 each) -- under 2e-4 units in all, a tenth of what the boxes were grown by; the window's
-// ends are off by less than 1e-4 units and RT_BOX_SLACK = 4e-3 units is given at either end.  So the
-// test only rejects rays that pass the primitive's part inside the node at a clear distance: the fp64
-// test, which accepts rays within ~1e-15 of the triangle and only hits inside the window, would
-// reject them too.  A direction component of zero gives inv = inf and tau = NaN for that axis;
+// units: 3e-5 each) -- under 2e-4 units in all, a tenth of the 2e-3 units of the boxes' growth that are
+// meant for it; the window's ends are off by less than 1e-4 units and RT_BOX_SLACK = 4e-3 units is given
+// at either end.  The rest of the growth covers the fp64 test itself: what it accepts lies within
+// 64 ulp * reach / 1e-5 of the triangle (tri_hit's guard bounds the conditioning), at most 2.8e-2 grid
+// units while the ray's reach is under RT_REACH_GRID units of the node's grid, and a ray with a longer
+// reach is not pre-tested in that node (node_step).  So the test only rejects rays that pass the
+// primitive's part inside the node at a clear distance, which the fp64 test, hitting only inside the
+// window, rejects too.  A direction component of zero gives inv = inf and tau = NaN for that axis;
 // minima and maxima skip a NaN, so the axis does not constrain the result, and a test whose
 // operands are all NaN passes.
 // RayB is the lane's ray for that test: inv (written whenever the ray's direction changes), c and
@@ -567,6 +573,17 @@ __device__ __forceinline__ void node_step(const DevScene &S, TravState &T, int &
         rb.ix = fi.x; rb.iy = fi.y; rb.iz = fi.z;
         rb.cx = -(gx * fi.x); rb.cy = -(gy * fi.y); rb.cz = -(gz * fi.z);
         rb.tend = (float)(n1 - n0) * dlen * sc + RT_BOX_SLACK;
+        {
+            // The boxes were grown for rays whose reach -- the largest coordinate of the origin plus the distance
+            // to the far end of the node's window -- is at most RT_REACH_GRID units of this node's grid: so far
+            // the double-precision test's own error stays inside the growth.  Beyond it (a node that is tiny
+            // against its distance from the ray's origin or from the coordinate origin) the pre-test says yes to
+            // everything in this run: a c of NaN makes every tau NaN, and a test of nothing but NaN passes.
+            const float reach = __builtin_fmaf((float)n1, dlen, (float)fmax(fmax(fabs(e.x), fabs(e.y)), fabs(e.z))) * sc;
+            const float off = __uint_as_float(0x7FC00000u);
+            const bool far = !(reach <= RT_REACH_GRID);
+            rb.cx = far ? off : rb.cx; rb.cy = far ? off : rb.cy; rb.cz = far ? off : rb.cz;
+        }
         // a run whose box the ray passes at a distance is covered without a look at its records
         open = has & box_pass(run_box.x, run_box.y, rb);
         c.box += has ? 1u : 0u;

@@ -122,8 +122,9 @@ inline void store_whole_node_box(uint32_t *dst) { dst[0] = 0xFF000000u; dst[1] =
 // An empty box: the single grid point (0, 0, 0), at least RT_GRID_ORG - 3 units outside the node's grown box
 // on every axis, so no ray reaches it inside the node's window.
 inline void store_empty_box(uint32_t *dst) { dst[0] = 0u; dst[1] = 0u; }
-// The box in the node's grid, rounded outwards: 2e-3 grid units beyond the bounds (the kernels'
-// single-precision arithmetic places the ray within 2e-4 units), then on to the next integer.
+// The box in the node's grid, rounded outwards: RT_BOX_GROW grid units beyond the bounds (the kernels'
+// single-precision arithmetic places the ray within 2e-4 units; the rest is for the error of the
+// double-precision primitive test, see rt_device.h), then on to the next integer.
 // grid_lo / grid_hi (nullable) receive the stored integers, for the union over a segment.
 inline void pack_box(uint32_t *dst, const BoxD &b, const FlatNode &n, float scale, int *grid_lo = nullptr, int *grid_hi = nullptr)
 {
@@ -140,7 +141,7 @@ inline void pack_box(uint32_t *dst, const BoxD &b, const FlatNode &n, float scal
     for (int k = 0; k < 3; k++) {
         const double glo = (b.lo[k] - n.lo[k]) * sc + (double)RT_GRID_ORG, ghi = (b.hi[k] - n.lo[k]) * sc + (double)RT_GRID_ORG;
         if (!std::isfinite(glo) || !std::isfinite(ghi)) return;
-        double l = std::floor(glo - 2e-3), h = std::ceil(ghi + 2e-3);
+        double l = std::floor(glo - RT_BOX_GROW), h = std::ceil(ghi + RT_BOX_GROW);
         if (l < 0) l = 0;
         if (h > 255) h = 255;
         if (l > 255 || h < 0) return;

@@ -238,7 +238,9 @@ def test_box_pretest_never_rejects_a_hit(case):
         lo, hi = off - 0.5, off + 1.5
     elif case == "slivers":
         tris = scenes.soup(6000, seed=92, edge_lo=1e-2, edge_hi=2e-1)
-        tris[:, 6:9] = tris[:, 0:3] + (tris[:, 3:6] - tris[:, 0:3]) * 0.5 + rng.normal(0, 1e-7, (len(tris), 3))   # third vertex on the first edge
+        # third vertex next to the middle of the first edge: needles with an angle of 1e-3 or so at v0 (thinner ones,
+        # below 1e-5, are no triangles to the primitive test: its determinant would be within reach of its rounding error)
+        tris[:, 6:9] = tris[:, 0:3] + (tris[:, 3:6] - tris[:, 0:3]) * 0.5 + rng.normal(0, 1e-4, (len(tris), 3))
         lo, hi = np.full(3, -0.5), np.full(3, 1.5)
     elif case == "flat":
         tris = scenes.soup(5000, seed=93, edge_lo=5e-3, edge_hi=5e-2)

@@ -37,7 +37,7 @@ static bool tri_hit(const LeafTri &tr, V e, V d, double t0, double t1, double &t
     V p = cross(d, e2);
     double det = dot(e1, p), a = std::fabs(det);
     if (!(a >= 1e-200)) return false;
-    if (!(det * det >= 1e-12 * dot(e1, e1) * dot(p, p))) return false;
+    if (!(det * det >= 1e-10 * dot(e1, e1) * dot(e2, e2) * dot(d, d))) return false;
     V s = e - v0;
     double up = dot(s, p), us = det < 0 ? -up : up;
     if (!(us >= 0.0 && us <= a)) return false;
@@ -74,7 +74,9 @@ int main(int argc, char **argv)
     fclose(f);
     FlatTree ft;
     std::string err;
-    if (!build_octree(tris.data(), tris.size() / 9, 1e-7, atoi(argv[2]), 3, atoi(argv[3]), ft, err)) { printf("%s\n", err.c_str()); return 1; }
+    const double pad = getenv("RT_PAD") ? atof(getenv("RT_PAD")) : 1e-7;
+    const int tol = getenv("RT_TOL") ? atoi(getenv("RT_TOL")) : 3;
+    if (!build_octree(tris.data(), tris.size() / 9, pad, atoi(argv[2]), tol, atoi(argv[3]), ft, err)) { printf("%s\n", err.c_str()); return 1; }
     V e{atof(argv[4]), atof(argv[5]), atof(argv[6])}, d{atof(argv[7]), atof(argv[8]), atof(argv[9])};
     const double t0 = atof(argv[10]), t1 = atof(argv[11]);
     printf("%zu nodes, %zu records\n", ft.nodes.size(), ft.leaf_tris.size());

@@ -18,6 +18,7 @@ from oracle import orc  # noqa: E402  (the checker)
 from raytracer_amd import hip, scenes  # noqa: E402
 from raytracer_amd.desc import LIGHT_DT, MAT_NORMAL, MATERIAL_DT, MISS, OBJ_GENUS2, OBJ_GROUND, OBJ_HEART, OBJECT_DT, RAY_DT, SceneDesc  # noqa: E402
 
+OCTREE_KNOBS = False          # also vary the insert policy's overlap tolerance and the triangles' box padding (--knobs)
 IMPLICIT_SHARE = 0.0          # share of the scenes that hold implicit surfaces (--implicit)
 
 
@@ -46,6 +47,12 @@ def random_scene(rng):
         if rng.random() < 0.3:
             objs.append(scenes.plane(OBJ_GROUND, float(rng.uniform(-1, 0)), 0))
     kw = dict(octree_max_size=int(rng.choice([2, 4, 8, 16, 32, 64, 128])), octree_max_depth=int(rng.integers(3, 16)))
+    if OCTREE_KNOBS:
+        # (a tolerance of 7 or 8 children, or a padding that is large against the smallest nodes, copies every
+        # triangle into all children level after level: trees that nobody can build)
+        kw["octree_overlap_tol"] = int(rng.integers(1, 6))
+        kw["tri_box_pad"] = float(rng.choice([0.0, 1e-12, 1e-7, 1e-5]))
+        kw["octree_max_depth"] = min(kw["octree_max_depth"], 9)
     if rng.random() < IMPLICIT_SHARE:
         # one or two implicit surfaces (voxel octrees) among the meshes, about as large as they are
         allv = np.concatenate([m.reshape(-1, 3) for m in meshes])
@@ -109,11 +116,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rays", type=int, default=20000)
     ap.add_argument("--implicit", type=float, default=0.0, help="share of the scenes with one or two implicit surfaces among the meshes")
+    ap.add_argument("--knobs", action="store_true", help="also vary octree_overlap_tol and tri_box_pad")
     ap.add_argument("--only", type=int, default=-1, help="evaluate this scene of the sequence alone")
     ap.add_argument("--oracle-only", action="store_true", help="build the scenes and run the oracle alone (checks this script without a GPU)")
     a = ap.parse_args()
-    global IMPLICIT_SHARE
+    global IMPLICIT_SHARE, OCTREE_KNOBS
     IMPLICIT_SHARE = a.implicit
+    OCTREE_KNOBS = a.knobs
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + a.seconds
     k = 0
