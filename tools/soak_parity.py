@@ -106,6 +106,10 @@ def random_rays(rng, meshes, n):
     d[lat] = (dl / np.maximum(nl, 1e-300))[lat]
     bad = np.linalg.norm(d, axis=1) == 0
     d[bad] = (0, 0, 1)
+    # one ray in twenty from far away, 1e2 .. 1e7 times the meshes' size back along its own line
+    far = rng.random(n) < 0.05
+    back = np.exp(rng.uniform(np.log(1e2), np.log(1e7), n)) * float(np.max(ext))
+    e[far] = (e - d * back[:, None])[far]
     r["e"], r["d"] = e, d
     return r
 
